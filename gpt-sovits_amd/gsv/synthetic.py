@@ -96,8 +96,8 @@ def small_vits_config():
     cfg["model"].update(
         {
             "inter_channels": 64,
-            "hidden_channels": 64,
-            "filter_channels": 128,
+            "hidden_channels": 192,   # fixed by MRTE()'s defaults (reference mrte_model.py:11-15)
+            "filter_channels": 256,
             "n_layers": 2,
             "upsample_rates": [4, 2, 2],
             "upsample_initial_channel": 128,
@@ -337,6 +337,11 @@ def make_vits_state_dict(config=None, seed: int = 0) -> "OrderedDict[str, torch.
     sd["ssl_proj.weight"] = _w("ssl_proj.weight", (SSL, SSL, 2), SSL * 2, 1.0, seed)
     sd["ssl_proj.bias"] = _b("ssl_proj.bias", SSL, 0.05, seed)
     sd["quantizer.vq.layers.0._codebook.embed"] = hash_symmetric("codebook.embed", (NBINS, SSL), 1.0, seed)
+    # EMA bookkeeping buffers present in real checkpoints (reference core_vq.py:106-109); `inited`
+    # must be true or the reference re-runs k-means on first use (core_vq.py:113-122)
+    sd["quantizer.vq.layers.0._codebook.inited"] = torch.ones(1)
+    sd["quantizer.vq.layers.0._codebook.cluster_size"] = torch.ones(NBINS)
+    sd["quantizer.vq.layers.0._codebook.embed_avg"] = sd["quantizer.vq.layers.0._codebook.embed"].clone()
     return sd
 
 

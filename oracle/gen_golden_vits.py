@@ -1,0 +1,110 @@
+"""TEST INFRASTRUCTURE ONLY -- golden vectors for the SoVITS decoder and the BigVGAN
+anti-alias activation, produced by running the REFERENCE classes imported from
+/root/reference (build container only).  See oracle/gen_golden.py."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "gpt-sovits_amd"))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from gsv import synthetic as S  # noqa: E402
+from oracle import ref_import  # noqa: E402
+from oracle.vits_oracle import VitsOracle  # noqa: E402
+from oracle import aa_oracle  # noqa: E402
+
+VITS_CASES = {
+    "vits_small": dict(cfg="small", seed=2, T=12, L=9, Tr=[30], noise_scale=0.5),
+    "vits_small_2ref": dict(cfg="small", seed=4, T=7, L=5, Tr=[24, 17], noise_scale=0.5),
+    "vits_v2": dict(cfg="v2", seed=0, T=10, L=8, Tr=[40], noise_scale=0.5),
+}
+
+
+def vits_case_inputs(case):
+    cfg = S.small_vits_config() if case["cfg"] == "small" else S.VITS_V2_CONFIG
+    sd = S.make_vits_state_dict(cfg, seed=case["seed"])
+    codes = torch.from_numpy(S.hash_ints("codes", case["T"], 1024, case["seed"])).view(1, 1, -1)
+    text = torch.from_numpy(S.hash_ints("text", case["L"], cfg["n_symbols"], case["seed"])).view(1, -1)
+    refers = [torch.from_numpy(S.hash_uniform(f"refer{i}", 1025 * tr, case["seed"]).reshape(1, 1025, tr).copy())
+              for i, tr in enumerate(case["Tr"])]
+    noise = S.hash_normal("vits_noise", (cfg["model"]["inter_channels"], 2 * case["T"]), case["seed"])
+    ssl = S.hash_symmetric("ssl", (1, 768, 2 * case["T"]), 1.0, case["seed"])
+    return cfg, sd, codes, text, refers, noise, ssl
+
+
+def build_reference_vits(cfg, sd):
+    cls = ref_import.synthesizer_cls()
+    d = cfg["data"]
+    model = cls(d["filter_length"] // 2 + 1, cfg["train"]["segment_size"] // d["hop_length"],
+                n_speakers=d["n_speakers"], version="v2", **cfg["model"])
+    res = model.load_state_dict(sd, strict=False)
+    bad = [k for k in res.missing_keys if not (k.startswith("enc_q") or "_codebook" in k)]
+    assert not bad and not res.unexpected_keys, (bad, res.unexpected_keys)
+    return model.eval()
+
+
+def gen_vits():
+    for name, case in VITS_CASES.items():
+        cfg, sd, codes, text, refers, noise, ssl = vits_case_inputs(case)
+        model = build_reference_vits(cfg, sd)
+        orig = torch.randn_like
+        torch.randn_like = lambda t, **kw: noise.unsqueeze(0).to(t.dtype)
+        try:
+            with torch.no_grad():
+                ref_wav = model.decode(codes, text, refers, noise_scale=case["noise_scale"])
+                ref_codes = model.extract_latent(ssl)
+        finally:
+            torch.randn_like = orig
+        orc = VitsOracle(sd, cfg)
+        col = {}
+        wav = orc.decode(codes, text, refers, noise_scale=case["noise_scale"], noise=noise, collect=col)
+        ocodes = orc.extract_latent(ssl)
+        err = (wav - ref_wav).abs().max().item()
+        print(f"[gen_golden] {name}: wav {tuple(ref_wav.shape)} |ref| max {ref_wav.abs().max():.3f} "
+              f"rms {ref_wav.pow(2).mean().sqrt():.3f}  oracle max-abs err {err:.2e}  "
+              f"codes match {torch.equal(ocodes, ref_codes)}")
+        for k, v in col.items():
+            print(f"     {k}: shape {tuple(v.shape)} absmax {v.abs().max():.3f} rms {v.pow(2).mean().sqrt():.3f}")
+        assert err <= 1e-4, "oracle restatement disagrees with the reference"
+        assert torch.equal(ocodes, ref_codes)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), wav=ref_wav.numpy().astype(np.float32),
+                            latent_codes=ref_codes.numpy().astype(np.int64),
+                            ge=col["ge"].numpy(), m_p=col["m_p"].numpy(), z=col["z"].numpy())
+
+
+def gen_aa():
+    """BigVGAN Activation1d(Snake / SnakeBeta) torch path on the reference's own test shape
+    (rand(10,10,200), BigVGAN/tests/test_activation.py:25)."""
+    ref_import.setup()
+    sys.path.insert(0, os.path.join(ref_import.REF_ROOT, "GPT_SoVITS", "BigVGAN"))
+    from alias_free_activation.torch.act import Activation1d
+    import activations as ract
+    for kind in ("snake", "snakebeta"):
+        C, T, B = 10, 200, 10
+        x = torch.from_numpy(S.hash_uniform("aa_x_" + kind, B * C * T, 1).reshape(B, C, T).copy())
+        la = S.hash_symmetric("aa_alpha_" + kind, (C,), 0.5, 1)
+        lb = S.hash_symmetric("aa_beta_" + kind, (C,), 0.5, 1)
+        act = (ract.Snake(C, alpha_logscale=True) if kind == "snake" else ract.SnakeBeta(C, alpha_logscale=True))
+        with torch.no_grad():
+            act.alpha.copy_(la)
+            if kind == "snakebeta":
+                act.beta.copy_(lb)
+            else:
+                lb = la
+            mod = Activation1d(activation=act)
+            ref = mod(x)
+        up_f, dn_f = mod.upsample.filter.view(-1), mod.downsample.lowpass.filter.view(-1)
+        ouf, odf = aa_oracle.default_filters()
+        out = aa_oracle.aa_activation(x, la, lb, ouf, odf)
+        err = (out - ref).abs().max().item()
+        print(f"[gen_golden] aa_{kind}: max-abs err {err:.2e}, filter err {(ouf - up_f).abs().max():.1e}")
+        assert err < 1e-5
+        np.savez_compressed(os.path.join(GOLD, f"aa_{kind}.npz"), out=ref.numpy(), up_filter=up_f.numpy(),
+                            down_filter=dn_f.numpy())
