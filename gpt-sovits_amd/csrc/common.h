@@ -1,0 +1,102 @@
+// gsv HIP library -- shared helpers (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/gsv.h"
+
+namespace gsv {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+void set_error(const char* fmt, ...);
+
+#define GSV_HIP(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      gsv::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return GSV_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+#define GSV_REQUIRE(cond, ...)                 \
+  do {                                         \
+    if (!(cond)) {                             \
+      gsv::set_error(__VA_ARGS__);             \
+      return GSV_ERR_ARG;                      \
+    }                                          \
+  } while (0)
+
+#define GSV_RC(e)            \
+  do {                       \
+    int _rc = (e);           \
+    if (_rc) return _rc;     \
+  } while (0)
+
+template <typename T> struct DT;
+template <> struct DT<float> { static constexpr int id = GSV_F32; static constexpr int G = 4; };
+template <> struct DT<_Float16> { static constexpr int id = GSV_F16; static constexpr int G = 8; };
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(_Float16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t dt_size(int dt) { return dt == GSV_F16 ? 2 : 4; }
+
+// ------------------------------------------------------------------------------------
+// generic channels-last implicit-GEMM conv (conv_gemm.hip)
+// ------------------------------------------------------------------------------------
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3 };
+
+struct ConvArgs {
+  const void* x = nullptr;   // [Z][T_in][ldx] activations, channels-last
+  const void* w = nullptr;   // [Z][Cout][ldw]  weights, K index = tap*Cin + cin (cin fastest)
+  const float* bias = nullptr;  // [Cout_real] fp32 or null
+  void* y = nullptr;         // [Z][T_out][ldy]
+  const void* res = nullptr; // residual, same dtype/shape convention as y (ldr)
+  int T_in = 0, T_out = 0;   // valid input rows / output rows actually stored
+  int T_virt = 0;            // number of GEMM columns computed (== T_out unless ups_u > 0)
+  int Cin = 0, Cout = 0, taps = 1;
+  int stride = 1, dil = 1, pad = 0;  // input row = t*stride + tap*dil - pad
+  int ldx = 0, ldw = 0, ldy = 0, ldr = 0;
+  int y_col0 = 0;            // column offset into y rows (for writing channel slices)
+  int pre_act = ACT_NONE;    // activation applied to x at load (ACT_LRELU uses pre_slope)
+  float pre_slope = 0.1f;
+  int post_act = ACT_NONE;   // activation applied after bias (+res)
+  float scale = 1.0f;        // v = (acc + bias + res) * scale
+  int accumulate = 0;        // y += v instead of y = v
+  int out_f32 = 0;           // y is fp32 regardless of T
+  int res_f32 = 0;           // res is fp32 regardless of T
+  int ups_u = 0, ups_pad = 0, ups_cout = 0;  // transposed-conv scatter: row = s*u + n/ups_cout - pad
+  int Z = 1;
+  long long xz = 0, wz = 0, yz = 0, rz = 0;  // batch strides in elements
+};
+int launch_conv_gemm(int dtype, const ConvArgs& a, hipStream_t s);
+
+// elementwise / small ops (ops.hip)
+int launch_layernorm(int dtype, const void* x, int x_f32, const void* res, int res_f32, const float* gamma,
+                     const float* beta, void* y, int y_f32, int rows, int C, float eps, hipStream_t s);
+int launch_convert(const float* src, void* dst, int dtype, long long n, hipStream_t s);
+
+}  // namespace gsv

@@ -1,0 +1,130 @@
+// Small shared kernels: error state, dtype conversion, row LayerNorm.
+#include "common.h"
+
+namespace gsv {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+template <typename T> __global__ void convert_kernel(const float* __restrict__ s, T* __restrict__ d, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) d[i] = (T)s[i];
+}
+
+int launch_convert(const float* src, void* dst, int dtype, long long n, hipStream_t s) {
+  if (n <= 0) return GSV_OK;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == GSV_F16) hipLaunchKernelGGL(convert_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, src, (_Float16*)dst, n);
+  else hipLaunchKernelGGL(convert_kernel<float>, dim3(blocks), dim3(256), 0, s, src, (float*)dst, n);
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+// One wave per row.  y = LN(x + res) * gamma + beta, statistics in fp32 (two-pass).
+template <typename TX, typename TR, typename TY>
+__global__ void layernorm_kernel(const TX* __restrict__ x, const TR* __restrict__ res, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, TY* __restrict__ y, int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const TX* xr = x + (long long)row * C;
+  const TR* rr = res ? res + (long long)row * C : nullptr;
+  float sum = 0.f;
+  for (int c = lane; c < C; c += 64) sum += to_f(xr[c]) + (rr ? to_f(rr[c]) : 0.f);
+  const float mean = wave_sum(sum) / (float)C;
+  float var = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    float d = to_f(xr[c]) + (rr ? to_f(rr[c]) : 0.f) - mean;
+    var += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(var) / (float)C + eps);
+  TY* yr = y + (long long)row * C;
+  for (int c = lane; c < C; c += 64) {
+    float v = to_f(xr[c]) + (rr ? to_f(rr[c]) : 0.f);
+    yr[c] = (TY)((v - mean) * rstd * gamma[c] + beta[c]);
+  }
+}
+
+template <typename TX, typename TR, typename TY>
+static int ln_launch(const void* x, const void* res, const float* g, const float* b, void* y, int rows, int C, float eps,
+                     hipStream_t s) {
+  hipLaunchKernelGGL((layernorm_kernel<TX, TR, TY>), dim3(cdiv(rows, 4)), dim3(256), 0, s, (const TX*)x, (const TR*)res,
+                     g, b, (TY*)y, rows, C, eps);
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+int launch_layernorm(int dtype, const void* x, int x_f32, const void* res, int res_f32, const float* gamma,
+                     const float* beta, void* y, int y_f32, int rows, int C, float eps, hipStream_t s) {
+  if (rows <= 0) return GSV_OK;
+  const bool h = dtype == GSV_F16;
+  const bool xf = x_f32 || !h, rf = res_f32 || !h, yf = y_f32 || !h;
+  if (xf && rf && yf) return ln_launch<float, float, float>(x, res, gamma, beta, y, rows, C, eps, s);
+  if (xf && rf && !yf) return ln_launch<float, float, _Float16>(x, res, gamma, beta, y, rows, C, eps, s);
+  if (xf && !rf && !yf) return ln_launch<float, _Float16, _Float16>(x, res, gamma, beta, y, rows, C, eps, s);
+  if (!xf && !rf && !yf) return ln_launch<_Float16, _Float16, _Float16>(x, res, gamma, beta, y, rows, C, eps, s);
+  if (!xf && !rf && yf) return ln_launch<_Float16, _Float16, float>(x, res, gamma, beta, y, rows, C, eps, s);
+  if (!xf && rf && !yf) return ln_launch<_Float16, float, _Float16>(x, res, gamma, beta, y, rows, C, eps, s);
+  set_error("layernorm: unsupported dtype combination");
+  return GSV_ERR_ARG;
+}
+
+}  // namespace gsv
+
+extern "C" {
+const char* gsv_last_error(void) { return gsv::get_error(); }
+int gsv_abi_version(void) { return 1; }
+int gsv_init(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    gsv::set_error("gsv_init: no HIP device (%s)", hipGetErrorString(e));
+    return GSV_ERR_HIP;
+  }
+  if (device < 0 || device >= n) {
+    gsv::set_error("gsv_init: device %d out of range (%d devices)", device, n);
+    return GSV_ERR_ARG;
+  }
+  GSV_HIP(hipSetDevice(device));
+  hipDeviceProp_t p;
+  GSV_HIP(hipGetDeviceProperties(&p, device));
+  if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+    gsv::set_error("gsv_init: device %d is %s, this library is built for gfx950 only", device, p.gcnArchName);
+    return GSV_ERR_HIP;
+  }
+  return GSV_OK;
+}
+
+int gsv_op_layernorm(const void* x, const void* res, const float* gamma, const float* beta, void* y, int rows, int C,
+                     float eps, int dtype, gsv_stream_t stream) {
+  return gsv::launch_layernorm(dtype, x, 0, res, 0, gamma, beta, y, 0, rows, C, eps, (hipStream_t)stream);
+}
+
+int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream) {
+  gsv::ConvArgs a;
+  a.x = d->x; a.w = d->w; a.bias = d->bias; a.y = d->y; a.res = d->res;
+  a.T_in = d->T_in; a.T_out = d->T_out; a.Cin = d->Cin; a.Cout = d->Cout; a.taps = d->taps;
+  a.stride = d->stride; a.dil = d->dil; a.pad = d->pad;
+  a.ldx = d->Cin; a.ldw = d->taps * d->Cin;
+  a.pre_act = d->pre_act; a.pre_slope = d->pre_slope; a.post_act = d->post_act; a.scale = d->scale;
+  a.accumulate = d->accumulate; a.out_f32 = d->out_f32; a.res_f32 = d->out_f32;
+  if (d->ups_u > 0) {
+    // transposed conv restated as a polyphase conv: Cout = u * real_cout virtual channels
+    a.ups_u = d->ups_u; a.ups_pad = d->ups_pad; a.ups_cout = d->Cout / d->ups_u;
+    a.ldy = a.ups_cout; a.ldr = a.ups_cout;
+    a.T_virt = d->T_in + d->taps - 1;
+  } else {
+    a.ldy = d->Cout; a.ldr = d->Cout;
+    a.T_virt = d->T_out;
+  }
+  return gsv::launch_conv_gemm(dtype, a, (hipStream_t)stream);
+}
+}

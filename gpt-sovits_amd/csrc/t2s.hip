@@ -1,0 +1,1152 @@
+// AR semantic-token decoder engine (H1-H5) for gfx950.
+//
+// State lives in HBM behind an opaque handle: weights in the engine dtype, a head-major KV
+// arena [layer][k|v][row][head][pos][head_dim] (so one (row, head) stream is contiguous and a
+// wave reads it as 1 KiB wave-instructions), per-row lengths/flags, and the token history.
+// The reference re-concatenates the cache every step (t2s_model.py:186-187) and
+// index_selects finished rows away on the host (:727-745); here rows are appended in place and
+// finished rows are flagged on the device, so a decode step has no host synchronisation and
+// is replayed as one hipGraph.
+//
+// Decode step = per layer 5 kernels (QKV+append, attention, out-proj, FFN1, FFN2), LayerNorm
+// fused into the consumer's prologue, split-K across the waves of a workgroup with an LDS
+// combine (no global partials), then logits + a one-wave-per-row sampling kernel.
+#include <math.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace gsv {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// device-side parameter block shared by the step kernels (lives in HBM so that the captured
+// graph does not bake sampling parameters)
+// ---------------------------------------------------------------------------------------
+struct StepParams {
+  int top_k;
+  float top_p;
+  float temperature;
+  float rep_penalty;
+  int early_stop_num;
+  int eos_mask_steps;
+  int max_steps;
+  int noise_rows;          // 0: counter RNG, 1: shared noise, B: per-row noise
+  unsigned long long seed;
+  const float* noise;      // [max_steps][noise_rows][V] or null
+  int* out_tokens;         // [B][max_steps]
+  int* out_len;            // [B]
+  int P;                   // prompt length (position offset of generated tokens)
+};
+
+// =======================================================================================
+// kernels
+// =======================================================================================
+
+// x[row] = E_text[id] + bert_proj(bert)[row] + alpha_t * pe[pos]     (H2; t2s_model.py:612-617)
+// or       E_audio[tok] + alpha_a * pe[pos]                            (t2s_model.py:636-640)
+// rows are packed per utterance: [x_0 .. x_{X-1}, y_0 .. y_{P-1}]
+template <typename T>
+__global__ void embed_prefill_kernel(const int* __restrict__ phones, const int* __restrict__ prompts,
+                                     const int* __restrict__ row_off, const int* __restrict__ ph_off,
+                                     const int* __restrict__ x_len, const float* __restrict__ e_text,
+                                     const float* __restrict__ e_audio, const float* __restrict__ bertp,  // [sumX][d] or null
+                                     const float* __restrict__ bert_bias, const float* __restrict__ pe, float alpha_t,
+                                     float alpha_a, int P, int d, T* __restrict__ x) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x;  // position within the row's sequence
+  const int X = x_len[b];
+  if (i >= X + P) return;
+  T* out = x + (long long)(row_off[b] + i) * d;
+  if (i < X) {
+    const int id = phones[ph_off[b] + i];
+    const float* e = e_text + (long long)id * d;
+    const float* bp = bertp ? bertp + (long long)(ph_off[b] + i) * d : nullptr;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+      float v = e[c] + (bp ? bp[c] : bert_bias[c]);
+      out[c] = (T)(v + alpha_t * pe[(long long)i * d + c]);
+    }
+  } else {
+    const int tok = prompts[b * P + (i - X)];
+    const float* e = e_audio + (long long)tok * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) out[c] = (T)(e[c] + alpha_a * pe[(long long)(i - X) * d + c]);
+  }
+}
+
+// scatter the prefill K/V (columns d..3d of qkv) into the head-major cache
+template <typename T>
+__global__ void kv_scatter_kernel(const T* __restrict__ qkv, const int* __restrict__ row_off, const int* __restrict__ x_len,
+                                  int P, int d, int H, int smax, T* __restrict__ kc, T* __restrict__ vc) {
+  const int b = blockIdx.y, i = blockIdx.x;
+  if (i >= x_len[b] + P) return;
+  const int hd = d / H;
+  const T* src = qkv + (long long)(row_off[b] + i) * 3 * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    const int h = c / hd, e = c - h * hd;
+    const long long o = (((long long)b * H + h) * smax + i) * hd + e;
+    kc[o] = src[d + c];
+    vc[o] = src[2 * d + c];
+  }
+}
+
+// Prefill attention (H3): one thread per query, keys streamed with a block-uniform address.
+// Mask (t2s_model.py:655-683): text rows see the text keys; audio rows see all text + causal audio.
+template <typename T, int HD>
+__global__ void prefill_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ kc, const T* __restrict__ vc,
+                                    const int* __restrict__ row_off, const int* __restrict__ x_len, int P, int d, int H,
+                                    int smax, T* __restrict__ out) {
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int X = x_len[b], S = X + P;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q0 = blockIdx.x * blockDim.x;
+  if (q0 >= S) return;
+  const bool valid = i < S;
+  const int nk = valid ? (i < X ? X : i + 1) : 0;
+  // block-uniform upper bound of the key loop
+  const int qlast = min(q0 + (int)blockDim.x, S) - 1;
+  const int nk_max = (qlast < X) ? X : qlast + 1;
+  float q[HD], acc[HD];
+  const T* qp = qkv + (long long)(row_off[b] + (valid ? i : 0)) * 3 * d + h * HD;
+  const float scale = rsqrtf((float)HD);
+#pragma unroll
+  for (int e = 0; e < HD; ++e) { q[e] = to_f(qp[e]) * scale; acc[e] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  const T* kb = kc + ((long long)b * H + h) * smax * HD;
+  const T* vb = vc + ((long long)b * H + h) * smax * HD;
+  for (int j = 0; j < nk_max; ++j) {
+    const T* kr = kb + (long long)j * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) s += q[e] * to_f(kr[e]);
+    if (j < nk) {
+      const float mn = fmaxf(m, s);
+      const float corr = expf(m - mn);
+      const float p = expf(s - mn);
+      const T* vr = vb + (long long)j * HD;
+      l = l * corr + p;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) acc[e] = acc[e] * corr + p * to_f(vr[e]);
+      m = mn;
+    }
+  }
+  if (valid) {
+    T* o = out + (long long)(row_off[b] + i) * d + h * HD;
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) o[e] = (T)(acc[e] * inv);
+  }
+}
+
+// gather each row's last prefill position of the fp32 pre-LN2 stream into the decode buffer
+__global__ void gather_last_kernel(const float* __restrict__ y2, const int* __restrict__ row_off,
+                                   const int* __restrict__ x_len, int P, int d, float* __restrict__ ybuf) {
+  const int b = blockIdx.x;
+  const float* src = y2 + (long long)(row_off[b] + x_len[b] + P - 1) * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) ybuf[(long long)b * d + c] = src[c];
+}
+
+// ---------------------------------------------------------------------------------------
+// Decode-step skinny GEMM:  Y[b][n] = sum_k X[b][k] W[n][k]   for b < B (B <= 16*CB)
+// Workgroup = one 16-row tile of W (n0..n0+15), NW waves each owning K/NW of the contraction,
+// partial 16x16 accumulators combined through LDS.  MFMA 16x16x32 f16 / 16x16x4 f32.
+// ---------------------------------------------------------------------------------------
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_RELU = 2, EPI_LOGITS = 3 };
+
+struct DecGemmArgs {
+  // X source (exactly one of yin / xin)
+  const float* yin;     // fp32 pre-LN stream [B][K] -> LN(gamma,beta) (or plain convert if gamma==null) -> LDS
+  const float* gamma;
+  const float* beta;
+  float* xres_out;      // if non-null, workgroup 0 writes the normalised fp32 rows here [B][K]
+  const void* xin;      // T activations [B][K] read straight from HBM/L2
+  const void* w;        // T [N][K]
+  const float* bias;    // [N] or null
+  int B, K, N;
+  int epi;
+  // epilogue targets
+  void* out_t;          // EPI_RELU: T [B][N]; EPI_QKV: q buffer T [B][d]
+  float* out_f;         // EPI_RESID / EPI_LOGITS: fp32 [B][N]
+  const float* xres;    // EPI_RESID: fp32 residual [B][N]
+  void* kc; void* vc;   // EPI_QKV: cache bases for this layer
+  const int* kv_len;    // EPI_QKV
+  const int* active;
+  int d, H, smax;
+};
+
+template <typename T> struct Frag16;
+template <> struct Frag16<_Float16> { typedef h8 type; static constexpr int KS = 32; };
+template <> struct Frag16<float> { typedef f4 type; static constexpr int KS = 16; };
+
+__device__ __forceinline__ void mma16(f4v& acc, const h8& a, const h8& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f4v& acc, const f4& a, const f4& b) {
+  // lane group g = lane>>4 holds k = k0 + 4g + i; MFMA i contracts {k0+i, k0+4+i, k0+8+i, k0+12+i}
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
+}
+
+template <typename T, int CB, int NW, bool LNPRO>
+__global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
+  typedef typename Frag16<T>::type F;
+  constexpr int G = DT<T>::G;
+  constexpr int KS = Frag16<T>::KS;  // k per MFMA group step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16;
+  const int K = a.K;
+  const int ldx = K + G;  // padded LDS row (elements): breaks the power-of-two row stride
+  T* xs = (T*)smem;
+  float* red = (float*)(smem + (LNPRO ? (size_t)CB * 16 * ldx * sizeof(T) : 0));
+
+  if (LNPRO) {
+    // one wave per row: two-pass LayerNorm in fp32 (reference F.layer_norm, eps 1e-5)
+    for (int row = wave; row < CB * 16; row += NW) {
+      T* dst = xs + (long long)row * ldx;
+      if (row >= a.B) {
+        for (int c = lane; c < K; c += 64) dst[c] = (T)0.f;
+        continue;
+      }
+      const float* src = a.yin + (long long)row * K;
+      if (a.gamma) {
+        float s = 0.f;
+        for (int c = lane; c < K; c += 64) s += src[c];
+        const float mean = wave_sum(s) / (float)K;
+        float v = 0.f;
+        for (int c = lane; c < K; c += 64) { float dlt = src[c] - mean; v += dlt * dlt; }
+        const float rstd = rsqrtf(wave_sum(v) / (float)K + 1e-5f);
+        for (int c = lane; c < K; c += 64) {
+          float o = (src[c] - mean) * rstd * a.gamma[c] + a.beta[c];
+          dst[c] = (T)o;
+          if (a.xres_out && blockIdx.x == 0) a.xres_out[(long long)row * K + c] = o;
+        }
+      } else {
+        for (int c = lane; c < K; c += 64) {
+          float o = src[c];
+          dst[c] = (T)o;
+          if (a.xres_out && blockIdx.x == 0) a.xres_out[(long long)row * K + c] = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  f4v acc[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) acc[cb] = (f4v){0.f, 0.f, 0.f, 0.f};
+
+  const int rowl = lane & 15, kg = lane >> 4;
+  const int kslice = K / NW;
+  const int kbeg = wave * kslice;
+  const bool wok = (n0 + rowl) < a.N;
+  const T* wrow = (const T*)a.w + (long long)(wok ? n0 + rowl : 0) * K;
+  const T* xg = (const T*)a.xin;
+#pragma unroll 4
+  for (int k0 = kbeg; k0 < kbeg + kslice; k0 += KS) {
+    const int k = k0 + G * kg;
+    F af;
+    if (wok) af = *(const F*)(wrow + k);
+    else {
+#pragma unroll
+      for (int i = 0; i < G; ++i) af[i] = 0;
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      F bf;
+      const int brow = cb * 16 + rowl;
+      if (LNPRO) {
+        bf = *(const F*)(xs + (long long)brow * ldx + k);
+      } else {
+        if (brow < a.B) bf = *(const F*)(xg + (long long)brow * K + k);
+        else {
+#pragma unroll
+          for (int i = 0; i < G; ++i) bf[i] = 0;
+        }
+      }
+      mma16(acc[cb], af, bf);
+    }
+  }
+  // combine the NW partial tiles through LDS (fixed summation order: deterministic)
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) *(f4v*)(red + ((wave * CB + cb) * 64 + lane) * 4) = acc[cb];
+  __syncthreads();
+  for (int item = tid; item < CB * 64; item += NW * 64) {
+    const int cb = item >> 6, ln = item & 63;
+    f4v v = (f4v){0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < NW; ++w) v += *(const f4v*)(red + ((w * CB + cb) * 64 + ln) * 4);
+    // D layout of 16x16: col = ln & 15 (batch row), rows 4*(ln>>4) + i (output channel)
+    const int b = cb * 16 + (ln & 15);
+    const int n = n0 + 4 * (ln >> 4);
+    if (b >= a.B || n >= a.N) continue;
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = v[i] + ((a.bias && n + i < a.N) ? a.bias[n + i] : 0.f);
+    if (a.epi == EPI_RESID) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (n + i < a.N) a.out_f[(long long)b * a.N + n + i] = o[i] + a.xres[(long long)b * a.N + n + i];
+    } else if (a.epi == EPI_RELU) {
+      T* op = (T*)a.out_t + (long long)b * a.N + n;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (n + i < a.N) op[i] = (T)fmaxf(o[i], 0.f);
+    } else if (a.epi == EPI_LOGITS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (n + i < a.N) a.out_f[(long long)b * a.N + n + i] = o[i];
+    } else {  // EPI_QKV: n in [0,3d): q -> qbuf, k/v -> cache row kv_len[b]
+      const int d = a.d, hd = d / a.H;
+      const int which = n / d, c = n - which * d;
+      if (which == 0) {
+        T* op = (T*)a.out_t + (long long)b * d + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) op[i] = (T)o[i];
+      } else if (a.active[b]) {
+        const int h = c / hd, e = c - h * hd;
+        const int pos = a.kv_len[b];
+        if (pos < a.smax) {
+          T* base = (T*)(which == 1 ? a.kc : a.vc);
+          T* op = base + (((long long)b * a.H + h) * a.smax + pos) * hd + e;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) op[i] = (T)o[i];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Decode attention (H4): one workgroup per (row, head); the KV stream of that pair is
+// contiguous [pos][hd], read as 16-byte lane loads (1 KiB per wave-instruction), keys dealt
+// round-robin to the 4 waves, per-lane online softmax, one LDS combine at the end.
+// This is the HBM-bound kernel of the step: algorithmic bytes = 2*hd*sizeof(T) per cached key.
+// ---------------------------------------------------------------------------------------
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
+                                                          const T* __restrict__ vc, const int* __restrict__ kv_len,
+                                                          const int* __restrict__ active, int H, int smax,
+                                                          T* __restrict__ out) {
+  constexpr int G = DT<T>::G;
+  constexpr int LPK = HD / G;      // lanes per key
+  constexpr int KPI = 64 / LPK;    // keys per wave-instruction
+  typedef typename Frag16<T>::type F;
+  const int h = blockIdx.x, b = blockIdx.y;
+  if (!active[b]) return;
+  const int n = min(kv_len[b] + 1, smax);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int part = lane % LPK, slot = lane / LPK;
+  const int d = H * HD;
+  float qf[G];
+  {
+    F qv = *(const F*)(q + (long long)b * d + h * HD + part * G);
+    const float scale = rsqrtf((float)HD);
+#pragma unroll
+    for (int i = 0; i < G; ++i) qf[i] = to_f(qv[i]) * scale;
+  }
+  const T* kb = kc + ((long long)b * H + h) * smax * HD;
+  const T* vb = vc + ((long long)b * H + h) * smax * HD;
+  float m = -INFINITY, l = 0.f, acc[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) acc[i] = 0.f;
+#pragma unroll 4
+  for (int j0 = wave * KPI; j0 < n; j0 += 4 * KPI) {
+    const int j = j0 + slot;
+    const bool ok = j < n;
+    F kv, vv;
+    if (ok) {
+      kv = *(const F*)(kb + (long long)j * HD + part * G);
+      vv = *(const F*)(vb + (long long)j * HD + part * G);
+    } else {
+#pragma unroll
+      for (int i = 0; i < G; ++i) { kv[i] = 0; vv[i] = 0; }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) s += qf[i] * to_f(kv[i]);
+#pragma unroll
+    for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (ok) {
+      const float mn = fmaxf(m, s);
+      const float corr = __expf(m - mn);
+      const float p = __expf(s - mn);
+      l = l * corr + p;
+#pragma unroll
+      for (int i = 0; i < G; ++i) acc[i] = acc[i] * corr + p * to_f(vv[i]);
+      m = mn;
+    }
+  }
+  // combine: global max, rescale, sum over key slots (lanes with equal `part`) and waves
+  __shared__ float s_m[4];
+  __shared__ float s_acc[4][HD + 1];
+  float wm = wave_max(m);
+  if (lane == 0) s_m[wave] = wm;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+  const float f = (m == -INFINITY) ? 0.f : __expf(m - M);
+  l *= f;
+#pragma unroll
+  for (int i = 0; i < G; ++i) acc[i] *= f;
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    l += __shfl_xor(l, o, 64);
+#pragma unroll
+    for (int i = 0; i < G; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+  }
+  if (lane < LPK) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) s_acc[wave][lane * G + i] = acc[i];
+    if (lane == 0) s_acc[wave][HD] = l;
+  }
+  __syncthreads();
+  if (threadIdx.x < HD) {
+    const int e = threadIdx.x;
+    const float L = s_acc[0][HD] + s_acc[1][HD] + s_acc[2][HD] + s_acc[3][HD];
+    const float v = s_acc[0][e] + s_acc[1][e] + s_acc[2][e] + s_acc[3][e];
+    out[(long long)b * d + h * HD + e] = (T)(v / L);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Sampling (H5): one wave per row, the whole row in registers (NPL values per lane), all
+// reductions are wavefront shuffles.  Semantics follow reference AR/models/utils.py:147-199:
+// repetition penalty (in place, so the EOS argmax test of t2s_model.py:721 sees penalised
+// logits) -> top-p on the un-tempered distribution -> /temperature -> top-k (ties kept) ->
+// softmax -> argmax(p / Exp(1)).  No sort: tokens are extracted in descending order only as
+// far as top-k / top-p need.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+struct ArgMax { float v; int i; };
+__device__ __forceinline__ ArgMax wave_argmax(float v, int i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+  return {v, i};
+}
+
+template <int NPL>
+__device__ void sample_row(const float* __restrict__ lg_row, int V, int Veff, const int* __restrict__ prev, int prev_len,
+                           int top_k, float top_p, float temperature, float rp, const float* __restrict__ noise_row,
+                           unsigned long long seed, int row, int step, unsigned char* seen /* LDS [V] */,
+                           int* out_sample, int* out_argmax) {
+  const int lane = threadIdx.x & 63;
+  float x[NPL];
+  // token v = lane + 64*i  (coalesced loads, low index first inside a lane)
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int v = lane + 64 * i;
+    x[i] = (v < Veff) ? lg_row[v] : -INFINITY;
+  }
+  if (rp != 1.0f) {
+    for (int v = lane; v < V; v += 64) seen[v] = 0;
+    __syncthreads();
+    for (int t = lane; t < prev_len; t += 64) {
+      int tok = prev[t];
+      if (tok >= 0 && tok < V) seen[tok] = 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int v = lane + 64 * i;
+      if (v < Veff && seen[v]) x[i] = (x[i] < 0.f) ? x[i] * rp : x[i] / rp;
+    }
+  }
+  // argmax of the penalised logits (first index on ties)
+  float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int v = lane + 64 * i;
+    if (v < Veff && (x[i] > bv)) { bv = x[i]; bi = v; }
+  }
+  ArgMax am = wave_argmax(bv, bi);
+  *out_argmax = am.i;
+  const float max0 = am.v;
+
+  const bool use_p = top_p < 1.0f;
+  const bool use_k = top_k > 0 && top_k < Veff;
+  unsigned int keep = 0;  // bit i: x[i] survives the filters
+  if (!use_p && !use_k) {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) if (lane + 64 * i < Veff) keep |= 1u << i;
+  } else {
+    float S = 1.f;
+    if (use_p) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) if (lane + 64 * i < Veff) s += expf(x[i] - max0);
+      S = wave_sum(s);
+    }
+    unsigned int taken = 0;
+    float cum = 0.f, pivot = 0.f;
+    bool have_pivot = false;
+    for (int r = 0; r < Veff; ++r) {
+      float cv = -INFINITY; int ci = 0x7fffffff; int cslot = -1;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int v = lane + 64 * i;
+        if (v < Veff && !((taken >> i) & 1u) && x[i] > cv) { cv = x[i]; ci = v; cslot = i; }
+      }
+      ArgMax e = wave_argmax(cv, ci);
+      if (e.i == 0x7fffffff || e.v == -INFINITY) break;  // nothing finite left
+      bool kept = true;
+      if (use_p) {
+        cum += expf(e.v - max0) / S;
+        if (r > 0 && cum > top_p) kept = false;
+      }
+      if (!kept) break;                  // top-p removes this and everything after it
+      if (use_k) {
+        if (r == top_k - 1) { pivot = e.v; have_pivot = true; }
+        else if (r >= top_k && !(have_pivot && e.v == pivot)) break;  // past the k-th value and not a tie
+      }
+      if (ci == e.i && cslot >= 0) {
+        // the owning lane marks the token as taken and kept
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) if (i == cslot) { taken |= 1u << i; keep |= 1u << i; }
+      }
+    }
+  }
+  // softmax over the kept set at temperature T, then the exponential race
+  const float tdiv = fmaxf(temperature, 1e-5f);
+  float lm = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) if ((keep >> i) & 1u) lm = fmaxf(lm, x[i] / tdiv);
+  lm = wave_max(lm);
+  float z = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) if ((keep >> i) & 1u) z += expf(x[i] / tdiv - lm);
+  z = wave_sum(z);
+  float sv = -INFINITY; int si = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int v = lane + 64 * i;
+    if (v >= Veff) continue;
+    float p = ((keep >> i) & 1u) ? expf(x[i] / tdiv - lm) / z : 0.f;
+    float qn;
+    if (noise_row) qn = noise_row[v];
+    else {
+      unsigned long long hsh = splitmix64(seed ^ splitmix64(((unsigned long long)row << 40) ^ ((unsigned long long)step << 20) ^ (unsigned long long)v));
+      float u = (float)(hsh >> 40) * (1.0f / 16777216.0f);
+      qn = fmaxf(-log1pf(-u), 1e-20f);
+    }
+    float sc = p / qn;
+    if (sc > sv) { sv = sc; si = v; }
+  }
+  ArgMax sm = wave_argmax(sv, si);
+  *out_sample = sm.i;
+}
+
+// step tail: sample every row, update row state, emit the next step's input embedding
+// (t2s_model.py:714-769).  grid = B, block = 64.
+template <int NPL>
+__global__ __launch_bounds__(64) void sample_step_kernel(const float* __restrict__ logits, int V, int EOS,
+                                                         const StepParams* __restrict__ spp, int* __restrict__ ytok,
+                                                         int ycap, int* __restrict__ kv_len, int* __restrict__ active,
+                                                         int* __restrict__ step_ctr, int* __restrict__ n_active,
+                                                         const float* __restrict__ e_audio, const float* __restrict__ pe,
+                                                         float alpha_a, int d, float* __restrict__ ybuf) {
+  extern __shared__ unsigned char seen[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const StepParams sp = *spp;
+  const int step = step_ctr[b];
+  if (!active[b]) return;
+  const int Veff = (step < sp.eos_mask_steps) ? V - 1 : V;
+  const int prev_len = sp.P + step;
+  int* yrow = ytok + (long long)b * ycap;
+  const float* nrow = nullptr;
+  if (sp.noise)
+    nrow = sp.noise + ((long long)step * sp.noise_rows + (sp.noise_rows > 1 ? b : 0)) * V;
+  int smp, amx;
+  sample_row<NPL>(logits + (long long)b * V, V, Veff, yrow, prev_len, sp.top_k, sp.top_p, sp.temperature,
+                  sp.rep_penalty, nrow, sp.seed, b, step, seen, &smp, &amx);
+  const bool fin = (smp == EOS) || (amx == EOS);
+  const bool early = (sp.early_stop_num != -1 && (step + 1) > sp.early_stop_num) || (step >= sp.max_steps - 1);
+  if (lane == 0) {
+    if (prev_len < ycap) yrow[prev_len] = smp;
+    if (fin || early) {
+      active[b] = 0;
+      sp.out_len[b] = step;
+      atomicSub(n_active, 1);
+    } else {
+      sp.out_tokens[(long long)b * sp.max_steps + step] = smp;
+      if (step > 0) kv_len[b] += 1;
+    }
+    step_ctr[b] = step + 1;
+  }
+  if (!(fin || early)) {
+    const int tok = min(max(smp, 0), V - 1);
+    const float* e = e_audio + (long long)tok * d;
+    const float* p = pe + (long long)(sp.P + step) * d;
+    for (int c = lane; c < d; c += 64) ybuf[(long long)b * d + c] = e[c] + alpha_a * p[c];
+  }
+}
+
+template <int NPL>
+__global__ __launch_bounds__(64) void sample_only_kernel(const float* __restrict__ logits, int V, int Veff,
+                                                         const int* __restrict__ prev, int prev_len, int top_k, float top_p,
+                                                         float temperature, float rp, const float* __restrict__ noise,
+                                                         unsigned long long seed, int step, int* __restrict__ sampled,
+                                                         int* __restrict__ argmax_tok) {
+  extern __shared__ unsigned char seen[];
+  const int b = blockIdx.x;
+  int smp, amx;
+  sample_row<NPL>(logits + (long long)b * V, V, Veff, prev + (long long)b * prev_len, prev_len, top_k, top_p, temperature,
+                  rp, noise ? noise + (long long)b * V : nullptr, seed, b, step, seen, &smp, &amx);
+  if (threadIdx.x == 0) { sampled[b] = smp; argmax_tok[b] = amx; }
+}
+
+}  // namespace gsv
+
+// =======================================================================================
+// engine
+// =======================================================================================
+using namespace gsv;
+
+struct LayerW {
+  void *qkv_w = nullptr, *out_w = nullptr, *w1 = nullptr, *w2 = nullptr;
+  float *qkv_b = nullptr, *out_b = nullptr, *b1 = nullptr, *b2 = nullptr;
+  float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr;
+};
+
+struct gsv_t2s {
+  gsv_t2s_config cfg;
+  int dtype, max_batch, max_seq;
+  bool finalized = false;
+  std::map<std::string, std::vector<float>> staged;
+  std::vector<LayerW> layers;
+  void* bert_w = nullptr; float* bert_b = nullptr;
+  float *e_text = nullptr, *e_audio = nullptr, *pe = nullptr;
+  void* pred_w = nullptr;
+  float alpha_t = 1.f, alpha_a = 1.f;
+  int pe_rows = 0;
+  // KV arena
+  void* kv = nullptr; size_t kv_layer_stride = 0;  // elements per (layer, k|v)
+  // row state
+  int *d_x_len = nullptr, *d_row_off = nullptr, *d_ph_off = nullptr, *d_kv_len = nullptr, *d_active = nullptr,
+      *d_step = nullptr, *d_n_active = nullptr, *d_ytok = nullptr;
+  int ycap = 0;
+  int* h_pinned = nullptr;
+  StepParams* d_sp = nullptr;
+  // decode buffers
+  float *ybuf = nullptr, *xres = nullptr, *logits = nullptr;
+  void *qbuf = nullptr, *abuf = nullptr, *hbuf = nullptr;
+  // prefill workspace (grown on demand)
+  size_t pf_rows = 0;
+  void *pf_x = nullptr, *pf_qkv = nullptr, *pf_attn = nullptr, *pf_h = nullptr;
+  float *pf_y = nullptr, *pf_bert = nullptr;
+  void* pf_bert_t = nullptr;
+  // current batch
+  int B = 0, P = 0;
+  std::map<int, hipGraphExec_t> graphs;
+  std::vector<void*> allocs;
+};
+
+namespace {
+
+size_t esz(const gsv_t2s* h) { return dt_size(h->dtype); }
+
+int dev_alloc(gsv_t2s* h, void** p, size_t bytes) {
+  GSV_HIP(hipMalloc(p, bytes ? bytes : 16));
+  h->allocs.push_back(*p);
+  return GSV_OK;
+}
+
+int upload_f32(gsv_t2s* h, const std::vector<float>& v, float** out) {
+  int rc = dev_alloc(h, (void**)out, v.size() * 4);
+  if (rc) return rc;
+  GSV_HIP(hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  return GSV_OK;
+}
+
+int upload_t(gsv_t2s* h, const std::vector<float>& v, void** out) {
+  if (h->dtype == GSV_F32) return upload_f32(h, v, (float**)out);
+  std::vector<_Float16> tmp(v.size());
+  for (size_t i = 0; i < v.size(); ++i) tmp[i] = (_Float16)v[i];
+  int rc = dev_alloc(h, out, tmp.size() * 2);
+  if (rc) return rc;
+  GSV_HIP(hipMemcpy(*out, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+  return GSV_OK;
+}
+
+const std::vector<float>* find(gsv_t2s* h, const std::string& k, size_t n) {
+  auto it = h->staged.find(k);
+  if (it == h->staged.end()) { set_error("t2s: missing tensor '%s'", k.c_str()); return nullptr; }
+  if (it->second.size() != n) {
+    set_error("t2s: tensor '%s' has %zu elements, expected %zu", k.c_str(), it->second.size(), n);
+    return nullptr;
+  }
+  return &it->second;
+}
+
+template <typename T, int CB, int NW, bool LNPRO>
+int launch_dec_gemm_inst(const DecGemmArgs& a, hipStream_t s) {
+  constexpr int G = DT<T>::G;
+  size_t lds = (size_t)NW * CB * 64 * 16;
+  if (LNPRO) lds += (size_t)CB * 16 * (a.K + G) * sizeof(T);
+  auto kern = dec_gemm_kernel<T, CB, NW, LNPRO>;
+  if (lds > 64 * 1024) GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(cdiv(a.N, 16)), dim3(NW * 64), lds, s, a);
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+template <typename T, int CB, bool LNPRO>
+int launch_dec_gemm_nw(const DecGemmArgs& a, hipStream_t s) {
+  constexpr int KS = Frag16<T>::KS;
+  // waves per workgroup: split K so that each wave keeps >= 4 k-steps when possible
+  int nw = 16;
+  while (nw > 1 && (a.K % (nw * KS) != 0 || a.K / nw < 4 * KS)) nw >>= 1;
+  if (a.K % (nw * KS) != 0) { set_error("dec_gemm: K=%d not a multiple of %d", a.K, KS); return GSV_ERR_ARG; }
+  switch (nw) {
+    case 16: return launch_dec_gemm_inst<T, CB, 16, LNPRO>(a, s);
+    case 8: return launch_dec_gemm_inst<T, CB, 8, LNPRO>(a, s);
+    case 4: return launch_dec_gemm_inst<T, CB, 4, LNPRO>(a, s);
+    case 2: return launch_dec_gemm_inst<T, CB, 2, LNPRO>(a, s);
+    default: return launch_dec_gemm_inst<T, CB, 1, LNPRO>(a, s);
+  }
+}
+
+template <typename T>
+int launch_dec_gemm(const DecGemmArgs& a, bool lnpro, hipStream_t s) {
+  const int cb = cdiv(a.B, 16);
+#define GSV_DG(CBV)                                                        \
+  return lnpro ? launch_dec_gemm_nw<T, CBV, true>(a, s) : launch_dec_gemm_nw<T, CBV, false>(a, s)
+  if (cb <= 1) { GSV_DG(1); }
+  if (cb <= 2) { GSV_DG(2); }
+  if (cb <= 4) { GSV_DG(4); }
+  if (cb <= 8) { GSV_DG(8); }
+#undef GSV_DG
+  set_error("dec_gemm: batch %d too large", a.B);
+  return GSV_ERR_ARG;
+}
+
+int sample_npl(int V) { return V <= 128 ? 2 : (V <= 1088 ? 17 : 32); }
+
+}  // namespace
+
+extern "C" {
+
+int gsv_t2s_create(const gsv_t2s_config* cfg, int dtype, int max_batch, int max_seq, gsv_t2s_t** out) {
+  GSV_REQUIRE(cfg && out, "t2s_create: null argument");
+  GSV_REQUIRE(dtype == GSV_F16 || dtype == GSV_F32, "t2s_create: bad dtype");
+  GSV_REQUIRE(cfg->dim % 64 == 0 && cfg->dim % cfg->n_head == 0, "t2s_create: dim must be a multiple of 64 and of n_head");
+  GSV_REQUIRE(cfg->dim / cfg->n_head == 32, "t2s_create: head_dim must be 32 (got %d)", cfg->dim / cfg->n_head);
+  GSV_REQUIRE(cfg->vocab <= 2048, "t2s_create: vocab %d > 2048", cfg->vocab);
+  GSV_REQUIRE(max_batch >= 1 && max_batch <= (dtype == GSV_F16 ? 128 : 64), "t2s_create: max_batch %d out of range", max_batch);
+  int n = 0;
+  GSV_HIP(hipGetDeviceCount(&n));
+  gsv_t2s* h = new gsv_t2s();
+  h->cfg = *cfg;
+  h->dtype = dtype;
+  h->max_batch = max_batch;
+  h->max_seq = max_seq;
+  h->layers.resize(cfg->n_layer);
+  *out = h;
+  return GSV_OK;
+}
+
+void gsv_t2s_destroy(gsv_t2s_t* h) {
+  if (!h) return;
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.second);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  delete h;
+}
+
+int gsv_t2s_load_tensor(gsv_t2s_t* h, const char* name, const float* data, int64_t numel) {
+  GSV_REQUIRE(h && name && data && numel > 0, "t2s_load_tensor: bad argument");
+  GSV_REQUIRE(!h->finalized, "t2s_load_tensor: handle already finalized");
+  std::string k(name);
+  if (k.rfind("model.", 0) == 0) k = k.substr(6);
+  h->staged[k].assign(data, data + numel);
+  return GSV_OK;
+}
+
+int gsv_t2s_finalize(gsv_t2s_t* h) {
+  GSV_REQUIRE(h && !h->finalized, "t2s_finalize: bad handle");
+  const auto& c = h->cfg;
+  const size_t d = c.dim, ff = c.ffn_dim, V = c.vocab, PV = c.phoneme_vocab, BD = c.bert_dim;
+  const std::vector<float>* t;
+#define GSV_GET(key, n) if (!(t = find(h, key, n))) return GSV_ERR_ARG
+  GSV_GET("bert_proj.weight", d * BD); GSV_RC(upload_t(h, *t, &h->bert_w));
+  GSV_GET("bert_proj.bias", d); GSV_RC(upload_f32(h, *t, &h->bert_b));
+  GSV_GET("ar_text_embedding.word_embeddings.weight", PV * d); GSV_RC(upload_f32(h, *t, &h->e_text));
+  GSV_GET("ar_audio_embedding.word_embeddings.weight", V * d); GSV_RC(upload_f32(h, *t, &h->e_audio));
+  GSV_GET("ar_text_position.alpha", 1); h->alpha_t = (*t)[0];
+  GSV_GET("ar_audio_position.alpha", 1); h->alpha_a = (*t)[0];
+  {
+    auto it = h->staged.find("pe");
+    GSV_REQUIRE(it != h->staged.end() && it->second.size() % d == 0, "t2s: missing sinusoid table 'pe' [n_pos][dim]");
+    h->pe_rows = (int)(it->second.size() / d);
+    GSV_RC(upload_f32(h, it->second, &h->pe));
+  }
+  GSV_GET("ar_predict_layer.weight", V * d); GSV_RC(upload_t(h, *t, &h->pred_w));
+  for (int i = 0; i < c.n_layer; ++i) {
+    std::string p = "h.layers." + std::to_string(i) + ".";
+    LayerW& L = h->layers[i];
+    GSV_GET(p + "self_attn.in_proj_weight", 3 * d * d); GSV_RC(upload_t(h, *t, &L.qkv_w));
+    GSV_GET(p + "self_attn.in_proj_bias", 3 * d); GSV_RC(upload_f32(h, *t, &L.qkv_b));
+    GSV_GET(p + "self_attn.out_proj.weight", d * d); GSV_RC(upload_t(h, *t, &L.out_w));
+    GSV_GET(p + "self_attn.out_proj.bias", d); GSV_RC(upload_f32(h, *t, &L.out_b));
+    GSV_GET(p + "linear1.weight", ff * d); GSV_RC(upload_t(h, *t, &L.w1));
+    GSV_GET(p + "linear1.bias", ff); GSV_RC(upload_f32(h, *t, &L.b1));
+    GSV_GET(p + "linear2.weight", d * ff); GSV_RC(upload_t(h, *t, &L.w2));
+    GSV_GET(p + "linear2.bias", d); GSV_RC(upload_f32(h, *t, &L.b2));
+    GSV_GET(p + "norm1.weight", d); GSV_RC(upload_f32(h, *t, &L.n1w));
+    GSV_GET(p + "norm1.bias", d); GSV_RC(upload_f32(h, *t, &L.n1b));
+    GSV_GET(p + "norm2.weight", d); GSV_RC(upload_f32(h, *t, &L.n2w));
+    GSV_GET(p + "norm2.bias", d); GSV_RC(upload_f32(h, *t, &L.n2b));
+  }
+#undef GSV_GET
+  h->staged.clear();
+  const size_t B = h->max_batch, es = esz(h);
+  h->kv_layer_stride = B * d * (size_t)h->max_seq;
+  GSV_RC(dev_alloc(h, &h->kv, (size_t)c.n_layer * 2 * h->kv_layer_stride * es));
+  GSV_RC(dev_alloc(h, (void**)&h->d_x_len, B * 4));
+  GSV_RC(dev_alloc(h, (void**)&h->d_row_off, B * 4));
+  GSV_RC(dev_alloc(h, (void**)&h->d_ph_off, B * 4));
+  GSV_RC(dev_alloc(h, (void**)&h->d_kv_len, B * 4));
+  GSV_RC(dev_alloc(h, (void**)&h->d_active, B * 4));
+  GSV_RC(dev_alloc(h, (void**)&h->d_step, B * 4));
+  GSV_RC(dev_alloc(h, (void**)&h->d_n_active, 16));
+  h->ycap = h->max_seq + 8;
+  GSV_RC(dev_alloc(h, (void**)&h->d_ytok, B * h->ycap * 4));
+  GSV_RC(dev_alloc(h, (void**)&h->d_sp, sizeof(StepParams)));
+  GSV_HIP(hipHostMalloc((void**)&h->h_pinned, 64));
+  GSV_RC(dev_alloc(h, (void**)&h->ybuf, B * d * 4));
+  GSV_RC(dev_alloc(h, (void**)&h->xres, B * d * 4));
+  GSV_RC(dev_alloc(h, (void**)&h->logits, B * V * 4));
+  GSV_RC(dev_alloc(h, &h->qbuf, B * d * es));
+  GSV_RC(dev_alloc(h, &h->abuf, B * d * es));
+  GSV_RC(dev_alloc(h, &h->hbuf, B * ff * es));
+  GSV_HIP(hipMemset(h->logits, 0, B * V * 4));
+  h->finalized = true;
+  return GSV_OK;
+}
+
+}  // extern "C"
+
+static void* kv_ptr(gsv_t2s* h, int layer, int which) {
+  return (char*)h->kv + ((size_t)(layer * 2 + which) * h->kv_layer_stride) * esz(h);
+}
+
+// logits (LN2 prologue of the last layer) + sampling/state update
+static int launch_tail(gsv_t2s* h, hipStream_t s) {
+  const auto& c = h->cfg;
+  DecGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  const LayerW& L = h->layers[c.n_layer - 1];
+  a.yin = h->ybuf; a.gamma = L.n2w; a.beta = L.n2b; a.w = h->pred_w; a.bias = nullptr;
+  a.B = h->B; a.K = c.dim; a.N = c.vocab; a.epi = EPI_LOGITS; a.out_f = h->logits;
+  int rc = h->dtype == GSV_F16 ? launch_dec_gemm<_Float16>(a, true, s) : launch_dec_gemm<float>(a, true, s);
+  if (rc) return rc;
+  const int V = c.vocab, EOS = c.vocab - 1;
+  const int npl = sample_npl(V);
+#define GSV_SAMPLE(N)                                                                                          \
+  hipLaunchKernelGGL(sample_step_kernel<N>, dim3(h->B), dim3(64), (size_t)((V + 15) & ~15), s, h->logits, V, EOS, h->d_sp, \
+                     h->d_ytok, h->ycap, h->d_kv_len, h->d_active, h->d_step, h->d_n_active, h->e_audio, h->pe,  \
+                     h->alpha_a, c.dim, h->ybuf)
+  if (npl == 2) GSV_SAMPLE(2);
+  else if (npl == 17) GSV_SAMPLE(17);
+  else GSV_SAMPLE(32);
+#undef GSV_SAMPLE
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+template <typename T>
+static int launch_decode_layers(gsv_t2s* h, hipStream_t s, int only_attn) {
+  const auto& c = h->cfg;
+  const int d = c.dim, H = c.n_head;
+  for (int li = 0; li < c.n_layer; ++li) {
+    const LayerW& L = h->layers[li];
+    if (!only_attn) {
+      DecGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.yin = h->ybuf;
+      if (li > 0) { a.gamma = h->layers[li - 1].n2w; a.beta = h->layers[li - 1].n2b; }
+      a.xres_out = h->xres;
+      a.w = L.qkv_w; a.bias = L.qkv_b; a.B = h->B; a.K = d; a.N = 3 * d; a.epi = EPI_QKV;
+      a.out_t = h->qbuf; a.kc = kv_ptr(h, li, 0); a.vc = kv_ptr(h, li, 1); a.kv_len = h->d_kv_len; a.active = h->d_active;
+      a.d = d; a.H = H; a.smax = h->max_seq;
+      GSV_RC(launch_dec_gemm<T>(a, true, s));
+    }
+    hipLaunchKernelGGL((decode_attn_kernel<T, 32>), dim3(H, h->B), dim3(256), 0, s, (const T*)h->qbuf,
+                       (const T*)kv_ptr(h, li, 0), (const T*)kv_ptr(h, li, 1), h->d_kv_len, h->d_active, H, h->max_seq,
+                       (T*)h->abuf);
+    if (only_attn) continue;
+    {
+      DecGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.xin = h->abuf; a.w = L.out_w; a.bias = L.out_b; a.B = h->B; a.K = d; a.N = d; a.epi = EPI_RESID;
+      a.out_f = h->ybuf; a.xres = h->xres;
+      GSV_RC(launch_dec_gemm<T>(a, false, s));
+    }
+    {
+      DecGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.yin = h->ybuf; a.gamma = L.n1w; a.beta = L.n1b; a.xres_out = h->xres;
+      a.w = L.w1; a.bias = L.b1; a.B = h->B; a.K = d; a.N = c.ffn_dim; a.epi = EPI_RELU; a.out_t = h->hbuf;
+      GSV_RC(launch_dec_gemm<T>(a, true, s));
+    }
+    {
+      DecGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.xin = h->hbuf; a.w = L.w2; a.bias = L.b2; a.B = h->B; a.K = c.ffn_dim; a.N = d; a.epi = EPI_RESID;
+      a.out_f = h->ybuf; a.xres = h->xres;
+      GSV_RC(launch_dec_gemm<T>(a, false, s));
+    }
+  }
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+static int launch_step(gsv_t2s* h, hipStream_t s) {
+  int rc = h->dtype == GSV_F16 ? launch_decode_layers<_Float16>(h, s, 0) : launch_decode_layers<float>(h, s, 0);
+  if (rc) return rc;
+  return launch_tail(h, s);
+}
+
+static int grow_prefill(gsv_t2s* h, size_t rows, size_t xrows) {
+  if (rows <= h->pf_rows) return GSV_OK;
+  const size_t d = h->cfg.dim, ff = h->cfg.ffn_dim, es = esz(h);
+  rows = (rows + 255) & ~(size_t)255;
+  // old buffers stay registered in allocs and are released at destroy; growth is rare
+  GSV_RC(dev_alloc(h, &h->pf_x, rows * d * es));
+  GSV_RC(dev_alloc(h, &h->pf_qkv, rows * 3 * d * es));
+  GSV_RC(dev_alloc(h, &h->pf_attn, rows * d * es));
+  GSV_RC(dev_alloc(h, &h->pf_h, rows * ff * es));
+  GSV_RC(dev_alloc(h, (void**)&h->pf_y, rows * d * 4));
+  GSV_RC(dev_alloc(h, (void**)&h->pf_bert, rows * d * 4));
+  GSV_RC(dev_alloc(h, &h->pf_bert_t, rows * (size_t)h->cfg.bert_dim * es));
+  h->pf_rows = rows;
+  (void)xrows;
+  return GSV_OK;
+}
+
+extern "C" {
+
+int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_lens, int B, const float* bert,
+                    const int32_t* prompts, int P, gsv_stream_t stream) {
+  GSV_REQUIRE(h && h->finalized, "t2s_prefill: handle not finalized");
+  GSV_REQUIRE(phones && phone_lens && prompts, "t2s_prefill: null argument");
+  GSV_REQUIRE(B >= 1 && B <= h->max_batch, "t2s_prefill: batch %d exceeds max_batch %d", B, h->max_batch);
+  GSV_REQUIRE(P >= 1, "t2s_prefill: prompt-free decode is not supported (P=%d)", P);
+  hipStream_t s = (hipStream_t)stream;
+  const auto& c = h->cfg;
+  const int d = c.dim, H = c.n_head;
+  std::vector<int> row_off(B), ph_off(B), kvl(B), ones(B, 1), zeros(B, 0);
+  int M = 0, SX = 0, maxS = 0;
+  for (int b = 0; b < B; ++b) {
+    GSV_REQUIRE(phone_lens[b] >= 1, "t2s_prefill: empty phoneme sequence in row %d", b);
+    row_off[b] = M; ph_off[b] = SX;
+    const int S = phone_lens[b] + P;
+    GSV_REQUIRE(S + 2 <= h->max_seq, "t2s_prefill: row %d needs %d positions, max_seq is %d", b, S + 2, h->max_seq);
+    GSV_REQUIRE(phone_lens[b] <= h->pe_rows && P <= h->pe_rows, "t2s_prefill: sequence exceeds the position table");
+    kvl[b] = S; M += S; SX += phone_lens[b];
+    maxS = S > maxS ? S : maxS;
+  }
+  GSV_RC(grow_prefill(h, M, SX));
+  h->B = B; h->P = P;
+  GSV_HIP(hipMemcpyAsync(h->d_x_len, phone_lens, B * 4, hipMemcpyHostToDevice, s));
+  GSV_HIP(hipMemcpyAsync(h->d_row_off, row_off.data(), B * 4, hipMemcpyHostToDevice, s));
+  GSV_HIP(hipMemcpyAsync(h->d_ph_off, ph_off.data(), B * 4, hipMemcpyHostToDevice, s));
+  GSV_HIP(hipMemcpyAsync(h->d_kv_len, kvl.data(), B * 4, hipMemcpyHostToDevice, s));
+  GSV_HIP(hipMemcpyAsync(h->d_active, ones.data(), B * 4, hipMemcpyHostToDevice, s));
+  GSV_HIP(hipMemcpyAsync(h->d_step, zeros.data(), B * 4, hipMemcpyHostToDevice, s));
+  GSV_HIP(hipMemcpyAsync(h->d_n_active, &B, 4, hipMemcpyHostToDevice, s));
+  GSV_HIP(hipMemcpy2DAsync(h->d_ytok, (size_t)h->ycap * 4, prompts, (size_t)P * 4, (size_t)P * 4, B, hipMemcpyDeviceToDevice, s));
+  GSV_HIP(hipStreamSynchronize(s));  // host vectors above go out of scope
+
+  const float* bertp = nullptr;
+  if (bert) {
+    GSV_RC(launch_convert(bert, h->pf_bert_t, h->dtype, (long long)SX * c.bert_dim, s));
+    ConvArgs g;
+    g.x = h->pf_bert_t; g.w = h->bert_w; g.bias = h->bert_b; g.y = h->pf_bert; g.out_f32 = 1;
+    g.T_in = SX; g.T_out = SX; g.T_virt = SX; g.Cin = c.bert_dim; g.Cout = d; g.ldx = c.bert_dim; g.ldw = c.bert_dim; g.ldy = d;
+    GSV_RC(launch_conv_gemm(h->dtype, g, s));
+    bertp = h->pf_bert;
+  }
+#define GSV_EMBED(T)                                                                                              \
+  hipLaunchKernelGGL(embed_prefill_kernel<T>, dim3(maxS, B), dim3(128), 0, s, phones, prompts, h->d_row_off, h->d_ph_off, \
+                     h->d_x_len, h->e_text, h->e_audio, bertp, h->bert_b, h->pe, h->alpha_t, h->alpha_a, P, d, (T*)h->pf_x)
+  if (h->dtype == GSV_F16) GSV_EMBED(_Float16); else GSV_EMBED(float);
+#undef GSV_EMBED
+  GSV_HIP(hipGetLastError());
+
+  for (int li = 0; li < c.n_layer; ++li) {
+    const LayerW& L = h->layers[li];
+    ConvArgs g;
+    g.x = h->pf_x; g.w = L.qkv_w; g.bias = L.qkv_b; g.y = h->pf_qkv;
+    g.T_in = M; g.T_out = M; g.T_virt = M; g.Cin = d; g.Cout = 3 * d; g.ldx = d; g.ldw = d; g.ldy = 3 * d;
+    GSV_RC(launch_conv_gemm(h->dtype, g, s));
+    if (h->dtype == GSV_F16) {
+      hipLaunchKernelGGL(kv_scatter_kernel<_Float16>, dim3(maxS, B), dim3(128), 0, s, (const _Float16*)h->pf_qkv,
+                         h->d_row_off, h->d_x_len, P, d, H, h->max_seq, (_Float16*)kv_ptr(h, li, 0), (_Float16*)kv_ptr(h, li, 1));
+      hipLaunchKernelGGL((prefill_attn_kernel<_Float16, 32>), dim3(cdiv(maxS, 64), H, B), dim3(64), 0, s,
+                         (const _Float16*)h->pf_qkv, (const _Float16*)kv_ptr(h, li, 0), (const _Float16*)kv_ptr(h, li, 1),
+                         h->d_row_off, h->d_x_len, P, d, H, h->max_seq, (_Float16*)h->pf_attn);
+    } else {
+      hipLaunchKernelGGL(kv_scatter_kernel<float>, dim3(maxS, B), dim3(128), 0, s, (const float*)h->pf_qkv, h->d_row_off,
+                         h->d_x_len, P, d, H, h->max_seq, (float*)kv_ptr(h, li, 0), (float*)kv_ptr(h, li, 1));
+      hipLaunchKernelGGL((prefill_attn_kernel<float, 32>), dim3(cdiv(maxS, 64), H, B), dim3(64), 0, s,
+                         (const float*)h->pf_qkv, (const float*)kv_ptr(h, li, 0), (const float*)kv_ptr(h, li, 1),
+                         h->d_row_off, h->d_x_len, P, d, H, h->max_seq, (float*)h->pf_attn);
+    }
+    GSV_HIP(hipGetLastError());
+    // y1 = attn Wo^T + bo + x  (fp32) ; x1 = LN1(y1)
+    ConvArgs o;
+    o.x = h->pf_attn; o.w = L.out_w; o.bias = L.out_b; o.y = h->pf_y; o.out_f32 = 1; o.res = h->pf_x; o.res_f32 = 0;
+    o.T_in = M; o.T_out = M; o.T_virt = M; o.Cin = d; o.Cout = d; o.ldx = d; o.ldw = d; o.ldy = d; o.ldr = d;
+    GSV_RC(launch_conv_gemm(h->dtype, o, s));
+    GSV_RC(launch_layernorm(h->dtype, h->pf_y, 1, nullptr, 0, L.n1w, L.n1b, h->pf_x, 0, M, d, 1e-5f, s));
+    ConvArgs f1;
+    f1.x = h->pf_x; f1.w = L.w1; f1.bias = L.b1; f1.y = h->pf_h; f1.post_act = ACT_RELU;
+    f1.T_in = M; f1.T_out = M; f1.T_virt = M; f1.Cin = d; f1.Cout = c.ffn_dim; f1.ldx = d; f1.ldw = d; f1.ldy = c.ffn_dim;
+    GSV_RC(launch_conv_gemm(h->dtype, f1, s));
+    ConvArgs f2;
+    f2.x = h->pf_h; f2.w = L.w2; f2.bias = L.b2; f2.y = h->pf_y; f2.out_f32 = 1; f2.res = h->pf_x; f2.res_f32 = 0;
+    f2.T_in = M; f2.T_out = M; f2.T_virt = M; f2.Cin = c.ffn_dim; f2.Cout = d; f2.ldx = c.ffn_dim; f2.ldw = c.ffn_dim;
+    f2.ldy = d; f2.ldr = d;
+    GSV_RC(launch_conv_gemm(h->dtype, f2, s));
+    if (li + 1 < c.n_layer)
+      GSV_RC(launch_layernorm(h->dtype, h->pf_y, 1, nullptr, 0, L.n2w, L.n2b, h->pf_x, 0, M, d, 1e-5f, s));
+  }
+  hipLaunchKernelGGL(gather_last_kernel, dim3(B), dim3(128), 0, s, h->pf_y, h->d_row_off, h->d_x_len, P, d, h->ybuf);
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noise, int noise_rows,
+                   int32_t* out_tokens, int32_t* out_len, int* steps_run, gsv_stream_t stream) {
+  GSV_REQUIRE(h && h->finalized && h->B > 0, "t2s_decode: call gsv_t2s_prefill first");
+  GSV_REQUIRE(sp && out_tokens && out_len, "t2s_decode: null argument");
+  GSV_REQUIRE(sp->max_steps >= 1, "t2s_decode: max_steps must be >= 1");
+  GSV_REQUIRE(noise == nullptr || noise_rows == 1 || noise_rows == h->B, "t2s_decode: noise_rows must be 1 or B");
+  hipStream_t s = (hipStream_t)stream;
+  StepParams p;
+  p.top_k = sp->top_k; p.top_p = sp->top_p; p.temperature = sp->temperature; p.rep_penalty = sp->repetition_penalty;
+  p.early_stop_num = sp->early_stop_num; p.eos_mask_steps = sp->eos_mask_steps; p.max_steps = sp->max_steps;
+  p.noise_rows = noise ? noise_rows : 0; p.seed = sp->seed; p.noise = noise; p.out_tokens = out_tokens; p.out_len = out_len;
+  p.P = h->P;
+  GSV_HIP(hipMemcpyAsync(h->d_sp, &p, sizeof(p), hipMemcpyHostToDevice, s));
+  GSV_HIP(hipStreamSynchronize(s));
+  // budget: every step appends one position
+  int kvmin_room = h->max_seq;
+  int budget = sp->max_steps;
+  if (sp->early_stop_num >= 0 && sp->early_stop_num + 1 < budget) budget = sp->early_stop_num + 1;
+  (void)kvmin_room;
+  // step 0: logits of the last prefill position, sample, emit first embedding
+  GSV_RC(launch_tail(h, s));
+  int steps = 1;
+  // steps >= 1 : captured once per batch size, replayed
+  hipGraphExec_t exec = nullptr;
+  auto it = h->graphs.find(h->B);
+  if (it != h->graphs.end()) exec = it->second;
+  else if (s != nullptr && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+    hipGraph_t graph;
+    int rc = launch_step(h, s);
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc) return rc;
+    GSV_HIP(e);
+    GSV_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    h->graphs[h->B] = exec;
+  } else {
+    (void)hipGetLastError();  // legacy default stream cannot capture: eager launches instead
+  }
+  const int check_every = 8;
+  while (steps < budget) {
+    if (exec) GSV_HIP(hipGraphLaunch(exec, s));
+    else GSV_RC(launch_step(h, s));
+    ++steps;
+    if (steps % check_every == 0 || steps == budget) {
+      GSV_HIP(hipMemcpyAsync(h->h_pinned, h->d_n_active, 4, hipMemcpyDeviceToHost, s));
+      GSV_HIP(hipStreamSynchronize(s));
+      if (h->h_pinned[0] <= 0) break;
+    }
+  }
+  GSV_HIP(hipStreamSynchronize(s));
+  if (steps_run) *steps_run = steps;
+  return GSV_OK;
+}
+
+int gsv_t2s_debug_logits(gsv_t2s_t* h, float* out, gsv_stream_t stream) {
+  GSV_REQUIRE(h && h->finalized && out && h->B > 0, "t2s_debug_logits: bad state");
+  GSV_HIP(hipMemcpyAsync(out, h->logits, (size_t)h->B * h->cfg.vocab * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return GSV_OK;
+}
+
+int64_t gsv_t2s_step_bytes(gsv_t2s_t* h, int64_t* attn_bytes) {
+  if (!h || !h->finalized) return 0;
+  const auto& c = h->cfg;
+  const int64_t es = (int64_t)esz(h), d = c.dim, ff = c.ffn_dim;
+  std::vector<int> kvl(h->B > 0 ? h->B : 1, 0), act(h->B > 0 ? h->B : 1, 0);
+  int64_t keys = 0;
+  if (h->B > 0) {
+    (void)hipMemcpy(kvl.data(), h->d_kv_len, h->B * 4, hipMemcpyDeviceToHost);
+    for (int b = 0; b < h->B; ++b) keys += kvl[b] + 1;
+  }
+  // per cached key and layer: K and V rows of d elements
+  const int64_t attn = keys * 2 * d * es;              // one layer's launch
+  const int64_t weights = ((int64_t)c.n_layer * (3 * d * d + d * d + 2 * d * ff) + (int64_t)c.vocab * d) * es;
+  if (attn_bytes) *attn_bytes = attn;
+  return weights + attn * c.n_layer + (int64_t)h->B * 2 * d * es * c.n_layer;
+}
+
+int gsv_t2s_time_step(gsv_t2s_t* h, int iters, float* step_ms, float* attn_ms, gsv_stream_t stream) {
+  GSV_REQUIRE(h && h->finalized && h->B > 0 && iters > 0, "t2s_time_step: bad state");
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  GSV_HIP(hipEventCreate(&e0));
+  GSV_HIP(hipEventCreate(&e1));
+  // attention kernel alone: 24 layers' caches back to back (472 MB at B=32,S=300 > Infinity Cache,
+  // so every launch streams from HBM)
+  int rc = GSV_OK;
+  for (int w = 0; w < 2 && !rc; ++w)
+    rc = h->dtype == GSV_F16 ? launch_decode_layers<_Float16>(h, s, 1) : launch_decode_layers<float>(h, s, 1);
+  GSV_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters && !rc; ++i)
+    rc = h->dtype == GSV_F16 ? launch_decode_layers<_Float16>(h, s, 1) : launch_decode_layers<float>(h, s, 1);
+  GSV_HIP(hipEventRecord(e1, s));
+  GSV_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  GSV_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (attn_ms) *attn_ms = ms / (float)(iters * h->cfg.n_layer);
+  if (step_ms) *step_ms = 0.f;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
+int gsv_op_sample(const float* logits, int B, int vocab, int vocab_eff, const int32_t* prev, int prev_len,
+                  const gsv_sampling_params* sp, const float* noise, int step, int32_t* sampled, int32_t* argmax_tok,
+                  gsv_stream_t stream) {
+  GSV_REQUIRE(logits && sp && sampled && argmax_tok && B > 0, "op_sample: null argument");
+  GSV_REQUIRE(vocab <= 2048 && vocab_eff <= vocab, "op_sample: vocab too large");
+  hipStream_t s = (hipStream_t)stream;
+  const int npl = sample_npl(vocab);
+  const size_t lds = (size_t)((vocab + 15) & ~15);
+#define GSV_SO(N)                                                                                                   \
+  hipLaunchKernelGGL(sample_only_kernel<N>, dim3(B), dim3(64), lds, s, logits, vocab, vocab_eff, prev, prev_len, sp->top_k, \
+                     sp->top_p, sp->temperature, sp->repetition_penalty, noise, (unsigned long long)sp->seed, step, sampled, \
+                     argmax_tok)
+  if (npl == 2) GSV_SO(2);
+  else if (npl == 17) GSV_SO(17);
+  else GSV_SO(32);
+#undef GSV_SO
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+}  // extern "C"

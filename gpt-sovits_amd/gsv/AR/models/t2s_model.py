@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference's `Text2SemanticDecoder` inference interface
+(reference GPT_SoVITS/AR/models/t2s_model.py:260-935), backed by the HIP engine.
+
+Same entry points, argument meaning and return values as the reference:
+`infer_panel_batch_infer` (:583), `infer_panel_naive_batched` (:781), `infer_panel_naive` (:814),
+`infer_panel` (:920).  All arithmetic (embeddings, prefill, KV-cached decode, sampling, EOS /
+early-stop bookkeeping) runs in libgsv_hip.so; this class only packs inputs and unpacks
+outputs.  There is no eager/PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from ... import _lib
+
+
+def _sine_pe(n_pos: int, dim: int) -> torch.Tensor:
+    """Position table, computed exactly as the reference does on the host
+    (AR/modules/embedding.py:54-72) so the fp32 engine sees bit-identical values."""
+    position = torch.arange(0, n_pos, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * -(math.log(10000.0) / dim))
+    pe = torch.zeros(n_pos, dim)
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+class Text2SemanticDecoder:
+    def __init__(self, config: dict, device="cuda:0", dtype=torch.float16, max_batch: int = 32,
+                 max_seq: int = 2048, norm_first: bool = False, top_k: int = 3):
+        m = config["model"]
+        self.config = config
+        self.model_dim = m["hidden_dim"]
+        self.embedding_dim = m["embedding_dim"]
+        self.num_head = m["head"]
+        self.num_layers = m["n_layer"]
+        self.vocab_size = m["vocab_size"]
+        self.phoneme_vocab_size = m["phoneme_vocab_size"]
+        self.EOS = m["EOS"]
+        assert self.EOS == self.vocab_size - 1
+        assert not norm_first, "the reference's inference checkpoints are post-LN"
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("gsv Text2SemanticDecoder runs on an MI355X (cuda/HIP device) only; "
+                               "there is no CPU path in the product")
+        self.dtype = dtype
+        self.max_batch = max_batch
+        self.max_seq = max_seq
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        with torch.cuda.device(self.device):
+            _lib.init(idx)
+            cfg = _lib.T2SConfig(self.num_layers, self.model_dim, self.num_head, 4 * self.model_dim,
+                                 self.vocab_size, self.phoneme_vocab_size, 1024)
+            h = C.c_void_p()
+            _lib.check(_lib.lib().gsv_t2s_create(C.byref(cfg), _lib.dtype_code(dtype), max_batch, max_seq,
+                                                 C.byref(h)), "gsv_t2s_create")
+            self._h = h
+            self.stream = torch.cuda.Stream(device=self.device)
+        self._loaded = False
+        self.infer_panel = self.infer_panel_naive
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().gsv_t2s_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ---- weights -------------------------------------------------------------------
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        """Accepts the reference checkpoint's `weight` dict (keys with or without the
+        Lightning `model.` prefix, reference TTS_infer_pack/TTS.py:590-603)."""
+        if self._loaded:
+            raise RuntimeError("weights already loaded; create a new Text2SemanticDecoder")
+        l = _lib.lib()
+        with torch.cuda.device(self.device):
+            for k, v in state_dict.items():
+                if not torch.is_tensor(v):
+                    continue
+                t = v.detach().to("cpu", torch.float32).contiguous()
+                _lib.check(l.gsv_t2s_load_tensor(self._h, k.encode(), t.data_ptr(), t.numel()), f"load {k}")
+            pe = _sine_pe(4000, self.embedding_dim).contiguous()
+            _lib.check(l.gsv_t2s_load_tensor(self._h, b"pe", pe.data_ptr(), pe.numel()), "load pe")
+            _lib.check(l.gsv_t2s_finalize(self._h), "gsv_t2s_finalize")
+        self._loaded = True
+        return self
+
+    # ---- engine call ---------------------------------------------------------------
+    def _run(self, x: Sequence[torch.Tensor], prompts: torch.Tensor, bert: Sequence[torch.Tensor], top_k, top_p,
+             early_stop_num, temperature, repetition_penalty, eos_mask_steps, noise=None, seed=0,
+             max_steps: int = 1500):
+        if not self._loaded:
+            raise RuntimeError("load_state_dict() first")
+        B = len(x)
+        if prompts is None:
+            raise NotImplementedError("prompt-free synthesis is outside the hot-path scope (SURVEY.md section 8)")
+        dev = self.device
+        l = _lib.lib()
+        with torch.cuda.device(dev):
+            lens = [int(t.shape[-1]) for t in x]
+            P = int(prompts.shape[1])
+            need = max(lens) + P + 2
+            budget = max_steps if early_stop_num in (-1, None) else min(max_steps, int(early_stop_num) + 1)
+            budget = min(budget, self.max_seq - need)
+            if budget < 1:
+                raise ValueError(f"sequence of {need} positions does not fit max_seq={self.max_seq}")
+            phones = torch.cat([t.reshape(-1) for t in x]).to(dev, torch.int32).contiguous()
+            lens_h = (C.c_int32 * B)(*lens)
+            bert_dev = None
+            if bert is not None:
+                nz = any(bool(torch.count_nonzero(b_).item()) for b_ in bert)
+                if nz:
+                    bert_dev = torch.cat([b_.reshape(1024, -1).t() for b_ in bert], 0).to(dev, torch.float32).contiguous()
+            pr = prompts.to(dev, torch.int32).contiguous()
+            out_tokens = torch.zeros(B, budget, dtype=torch.int32, device=dev)
+            out_len = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            noise_dev, noise_rows = None, 0
+            if noise is not None:
+                noise_dev = noise.to(dev, torch.float32).contiguous()
+                assert noise_dev.dim() == 3 and noise_dev.shape[2] == self.vocab_size and noise_dev.shape[0] >= budget
+                noise_rows = noise_dev.shape[1]
+                noise_dev = noise_dev[:budget].contiguous()
+            self.stream.wait_stream(torch.cuda.current_stream(dev))
+            sp = _lib.SamplingParams(int(top_k) if top_k is not None else 0, float(top_p if top_p is not None else 1.0),
+                                     float(temperature), float(repetition_penalty),
+                                     -1 if early_stop_num is None else int(early_stop_num), int(eos_mask_steps),
+                                     int(budget), int(seed) & 0xFFFFFFFFFFFFFFFF)
+            if early_stop_num not in (-1, None) and budget < int(early_stop_num) + 1:
+                sp.early_stop_num = -1   # the arena bound (max_steps) ends generation first
+            s = C.c_void_p(self.stream.cuda_stream)
+            _lib.check(l.gsv_t2s_prefill(self._h, phones.data_ptr(), C.cast(lens_h, C.c_void_p), B,
+                                         bert_dev.data_ptr() if bert_dev is not None else None, pr.data_ptr(), P, s),
+                       "gsv_t2s_prefill")
+            steps = C.c_int(0)
+            _lib.check(l.gsv_t2s_decode(self._h, C.byref(sp), noise_dev.data_ptr() if noise_dev is not None else None,
+                                        noise_rows, out_tokens.data_ptr(), out_len.data_ptr(), C.byref(steps), s),
+                       "gsv_t2s_decode")
+            torch.cuda.current_stream(dev).wait_stream(self.stream)
+            idx = out_len.cpu().tolist()
+            self.last_steps = steps.value
+            y_list = []
+            for b in range(B):
+                n = idx[b] if idx[b] >= 0 else steps.value - 1
+                idx[b] = n
+                y_list.append(torch.cat([pr[b].long(), out_tokens[b, :n].long()]))
+        return y_list, idx
+
+    # ---- reference entry points -----------------------------------------------------
+    @torch.no_grad()
+    def infer_panel_batch_infer(self, x: List[torch.LongTensor], x_lens: torch.LongTensor, prompts: torch.LongTensor,
+                                bert_feature: List[torch.Tensor], top_k: int = -100, top_p: int = 100,
+                                early_stop_num: int = -1, temperature: float = 1.0,
+                                repetition_penalty: float = 1.35, **kwargs):
+        """reference t2s_model.py:583-779: returns (y_list, idx_list); y_list[i] = prompt + generated
+        tokens (finishing token dropped), idx_list[i] = number of generated tokens."""
+        if prompts is None:
+            return self.infer_panel_naive_batched(x, x_lens, prompts, bert_feature, top_k=top_k, top_p=top_p,
+                                                  early_stop_num=early_stop_num, temperature=temperature, **kwargs)
+        out = []
+        ys: List[Optional[torch.Tensor]] = [None] * len(x)
+        idxs: List[Optional[int]] = [None] * len(x)
+        noise = kwargs.get("noise")
+        for lo in range(0, len(x), self.max_batch):
+            hi = min(lo + self.max_batch, len(x))
+            nz = noise
+            if noise is not None and noise.shape[1] > 1:
+                nz = noise[:, lo:hi]
+            y, i = self._run(x[lo:hi], prompts[lo:hi], bert_feature[lo:hi], top_k, top_p, early_stop_num, temperature,
+                             repetition_penalty, eos_mask_steps=1, noise=nz, seed=kwargs.get("seed", 0),
+                             max_steps=kwargs.get("max_steps", 1500))
+            ys[lo:hi] = y
+            idxs[lo:hi] = i
+        return ys, idxs
+
+    @torch.no_grad()
+    def infer_panel_naive(self, x: torch.LongTensor, x_lens: torch.LongTensor, prompts: torch.LongTensor,
+                          bert_feature: torch.Tensor, top_k: int = -100, top_p: int = 100, early_stop_num: int = -1,
+                          temperature: float = 1.0, repetition_penalty: float = 1.35, **kwargs):
+        """reference t2s_model.py:814-918: batch 1, EOS masked while idx < 11; returns (y[:, :-1], idx)."""
+        y, i = self._run([x[0]], prompts, [bert_feature[0]], top_k, top_p, early_stop_num, temperature,
+                         repetition_penalty, eos_mask_steps=11, noise=kwargs.get("noise"), seed=kwargs.get("seed", 0),
+                         max_steps=kwargs.get("max_steps", 1500))
+        return y[0].unsqueeze(0), i[0]
+
+    @torch.no_grad()
+    def infer_panel_naive_batched(self, x, x_lens, prompts, bert_feature, top_k: int = -100, top_p: int = 100,
+                                  early_stop_num: int = -1, temperature: float = 1.0,
+                                  repetition_penalty: float = 1.35, **kwargs):
+        """reference t2s_model.py:781-812: the naive loop per item."""
+        y_list, idx_list = [], []
+        for i in range(len(x)):
+            y, idx = self.infer_panel_naive(x[i].unsqueeze(0), x_lens[i] if x_lens is not None else None,
+                                            prompts[i].unsqueeze(0) if prompts is not None else None,
+                                            bert_feature[i].unsqueeze(0), top_k, top_p, early_stop_num, temperature,
+                                            repetition_penalty, **kwargs)
+            y_list.append(y[0])
+            idx_list.append(idx)
+        return y_list, idx_list
+
+    # ---- measurement hooks (bench.py) ----------------------------------------------
+    def debug_logits(self, B: int) -> torch.Tensor:
+        out = torch.empty(B, self.vocab_size, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().gsv_t2s_debug_logits(self._h, out.data_ptr(), C.c_void_p(self.stream.cuda_stream)))
+            self.stream.synchronize()
+        return out
+
+    def time_attention(self, iters: int = 20):
+        """(avg ms per decode-attention launch, algorithmic HBM bytes per launch) at the current cache state."""
+        ms = C.c_float(0)
+        step = C.c_float(0)
+        ab = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            l = _lib.lib()
+            _lib.check(l.gsv_t2s_time_step(self._h, iters, C.byref(step), C.byref(ms), C.c_void_p(self.stream.cuda_stream)))
+            total = l.gsv_t2s_step_bytes(self._h, C.byref(ab))
+        return ms.value, ab.value, total

@@ -1,0 +1,172 @@
+/* gsv.h -- C ABI of libgsv_hip.so, the MI355X (gfx950) GPT-SoVITS synthesis hot path.
+ *
+ * Drop-in boundary.  Each group of entry points replaces one seam
+ * of the reference (paths under /root/reference/GPT_SoVITS):
+ *
+ *   gsv_t2s_*    <- Text2SemanticDecoder.infer_panel_batch_infer / infer_panel_naive
+ *                   AR/models/t2s_model.py:583-779, 814-918 (called from
+ *                   TTS_infer_pack/TTS.py:1215-1227 and inference_webui.py:878);
+ *                   sampling AR/models/utils.py:140-199
+ *   gsv_vits_*   <- SynthesizerTrn.decode / extract_latent, module/models.py:961-1010
+ *                   (called from TTS_infer_pack/TTS.py:1271, 818; inference_webui.py:920)
+ *   gsv_aa_act_forward <- anti_alias_activation_cuda.forward, the reference's only native
+ *                   FFI: BigVGAN/alias_free_activation/cuda/anti_alias_activation.cpp:19-22,
+ *                   anti_alias_activation_cuda.cu:212-246
+ *   gsv_op_*     <- single kernels exposed for parity tests
+ *
+ * Conventions: plain C, no torch types.  Pointers marked [dev] are device (HBM) pointers owned
+ * by the caller; [host] are host pointers.  `stream` is a hipStream_t passed as void*.
+ * Every function returns GSV_OK (0) or a negative error code; gsv_last_error() returns a
+ * thread-local message.  Handles are re-entrant per handle: one handle, one stream at a time.
+ * There is no CPU fallback: every entry point fails with GSV_ERR_HIP if no gfx950 device exists.
+ */
+#ifndef GSV_H_
+#define GSV_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSV_OK 0
+#define GSV_ERR_ARG (-1)
+#define GSV_ERR_HIP (-2)
+#define GSV_ERR_STATE (-3)
+
+#define GSV_F32 0 /* fp32 storage, exact-f32 MFMA: parity mode                      */
+#define GSV_F16 1 /* fp16 storage, fp32 accumulation: production mode (is_half=True) */
+
+typedef void* gsv_stream_t;
+
+int gsv_init(int device);
+const char* gsv_last_error(void);
+int gsv_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * AR semantic-token decoder (H1-H5)
+ * ------------------------------------------------------------------------------------- */
+typedef struct gsv_t2s gsv_t2s_t;
+
+typedef struct {
+  int n_layer;        /* 24 */
+  int dim;            /* 512 */
+  int n_head;         /* 16 */
+  int ffn_dim;        /* 4*dim (t2s_model.py:304) */
+  int vocab;          /* 1025, EOS = vocab-1 */
+  int phoneme_vocab;  /* 732 (v2) / 512 (v1) */
+  int bert_dim;       /* 1024 */
+} gsv_t2s_config;
+
+typedef struct {
+  int top_k;                /* <=0: disabled */
+  float top_p;              /* >=1: disabled */
+  float temperature;
+  float repetition_penalty;
+  int early_stop_num;       /* -1: none; else stop once generated > early_stop_num (t2s_model.py:747) */
+  int eos_mask_steps;       /* EOS column dropped while step < this: 1 for the batched loop
+                               (t2s_model.py:708-710), 11 for infer_panel_naive (:888-889) */
+  int max_steps;            /* reference hard cap 1500 (t2s_model.py:701) */
+  uint64_t seed;            /* counter-RNG key for the Exp(1) race when no noise is injected */
+} gsv_sampling_params;
+
+int gsv_t2s_create(const gsv_t2s_config* cfg, int dtype, int max_batch, int max_seq, gsv_t2s_t** out);
+void gsv_t2s_destroy(gsv_t2s_t* h);
+/* name = reference state-dict key without the "model." prefix;
+ * data [host] fp32, numel elements. */
+int gsv_t2s_load_tensor(gsv_t2s_t* h, const char* name, const float* data, int64_t numel);
+int gsv_t2s_finalize(gsv_t2s_t* h);
+
+/* Prefill (H2+H3): phones [dev] int32 packed, phone_lens [host] int32[B], bert [dev] fp32
+ * [sum(X_b)][bert_dim] row-major (token-major; NULL = all zeros, the non-zh path), prompts [dev]
+ * int32 [B][P].  Leaves the KV cache and per-row state ready for gsv_t2s_decode. */
+int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_lens, int B,
+                    const float* bert, const int32_t* prompts, int P, gsv_stream_t stream);
+
+/* Decode loop (H4+H5).  noise [dev] fp32 Exp(1) draws [max_steps][noise_rows][vocab] or NULL
+ * (noise_rows is 1 = shared by all rows, or B).  out_tokens [dev] int32 [B][max_steps]: generated
+ * tokens (the finishing EOS / overflow token is not counted); out_len [dev] int32 [B] = the
+ * reference's idx_list.  steps_run [host] receives the number of steps executed. */
+int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noise, int noise_rows,
+                   int32_t* out_tokens, int32_t* out_len, int* steps_run, gsv_stream_t stream);
+
+/* test hooks: logits of the last completed step [dev] fp32 [B][vocab] */
+int gsv_t2s_debug_logits(gsv_t2s_t* h, float* out, gsv_stream_t stream);
+/* per-kernel timing of the decode step: average device time (ms) of one step over `iters`
+ * replays at the current cache length, and of the decode-attention kernel alone. */
+int gsv_t2s_time_step(gsv_t2s_t* h, int iters, float* step_ms, float* attn_ms, gsv_stream_t stream);
+/* algorithmic HBM bytes of one decode step at the current state */
+int64_t gsv_t2s_step_bytes(gsv_t2s_t* h, int64_t* attn_bytes);
+
+/* ---------------------------------------------------------------------------------------
+ * SoVITS v2 waveform decoder (H6-H12)
+ * ------------------------------------------------------------------------------------- */
+typedef struct gsv_vits gsv_vits_t;
+
+typedef struct {
+  int inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size;
+  int gin_channels, n_symbols, ssl_dim, n_bins, upsample_initial_channel;
+  int n_ups;
+  int up_rates[8];
+  int up_kernels[8];
+  int n_resblocks;          /* resblocks per stage (3) */
+  int rb_kernels[4];
+  int rb_dilations[4][3];
+  int ref_bins;             /* 704 (v2): leading spectrogram bins fed to ref_enc */
+} gsv_vits_config;
+
+int gsv_vits_create(const gsv_vits_config* cfg, int dtype, gsv_vits_t** out);
+void gsv_vits_destroy(gsv_vits_t* h);
+int gsv_vits_load_tensor(gsv_vits_t* h, const char* name, const float* data, int64_t numel);
+int gsv_vits_finalize(gsv_vits_t* h); /* folds weight-norm, repacks conv weights */
+
+/* ge = mean over references of ref_enc(spec[:ref_bins]) (models.py:962-984).  specs [host] array
+ * of n_refs [dev] fp32 pointers, each [bins][frames[i]] channels-first as the reference holds it. */
+int gsv_vits_set_refer(gsv_vits_t* h, const float* const* specs, const int* frames, int bins, int n_refs,
+                       gsv_stream_t stream);
+/* codes [dev] int32 [T], phones [dev] int32 [L], noise [dev] fp32 [inter][2T] channels-first
+ * (the randn_like draw of models.py:1000; NULL = counter RNG keyed by seed), wav [dev] fp32
+ * [2T * prod(up_rates)]. */
+int gsv_vits_decode(gsv_vits_t* h, const int32_t* codes, int T, const int32_t* phones, int L, const float* noise,
+                    float noise_scale, uint64_t seed, float* wav, gsv_stream_t stream);
+/* ssl [dev] fp32 [ssl_dim][T50] channels-first -> codes [dev] int32 [T50/2] */
+int gsv_vits_extract_latent(gsv_vits_t* h, const float* ssl, int T50, int32_t* codes, gsv_stream_t stream);
+/* test hook: copy a named intermediate of the last decode ("ge","m_p","logs_p","z","stage0".."stage4")
+ * into out [dev] fp32 in channels-first [C][T] order; returns element count via *numel. */
+int gsv_vits_debug_tensor(gsv_vits_t* h, const char* name, float* out, int64_t cap, int64_t* numel,
+                          gsv_stream_t stream);
+/* per-kernel timing hooks for bench.py: device ms of the last decode's generator section */
+int gsv_vits_last_timing(gsv_vits_t* h, float* total_ms, float* generator_ms);
+
+/* ---------------------------------------------------------------------------------------
+ * BigVGAN anti-aliased snake activation (v3 vocoder), the reference's one native kernel.
+ * x,y [dev] [B][C][T] of `dtype`; up12/dn12 [dev] 12 filter taps; log_alpha/log_beta [dev] [C].
+ * T == 0 returns GSV_OK without a launch (anti_alias_activation_cuda.cu:193-196).
+ * ------------------------------------------------------------------------------------- */
+int gsv_aa_act_forward(const void* x, void* y, const void* up12, const void* dn12, const void* log_alpha,
+                       const void* log_beta, int B, int C, int T, int dtype, gsv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * single-kernel test entry points
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x; const void* w; const float* bias; void* y; const void* res;
+  int T_in, T_out, Cin, Cout, taps, stride, dil, pad;
+  int pre_act; float pre_slope; int post_act; float scale; int accumulate; int out_f32;
+  int ups_u, ups_pad;
+} gsv_conv_desc;
+/* channels-last conv1d: x [T_in][Cin], w [Cout][taps*Cin] (tap-major, cin fastest), y [T_out][Cout] */
+int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream);
+/* y = LN(x (+res)) over the last dim C; all buffers of `dtype`, gamma/beta fp32 */
+int gsv_op_layernorm(const void* x, const void* res, const float* gamma, const float* beta, void* y, int rows,
+                     int C, float eps, int dtype, gsv_stream_t stream);
+/* sampling kernel alone: logits [dev] fp32 [B][vocab], prev [dev] int32 [B][prev_len], noise [dev]
+ * fp32 [B][vocab] or NULL; outputs [dev] int32 [B]: sampled token, argmax of penalised logits */
+int gsv_op_sample(const float* logits, int B, int vocab, int vocab_eff, const int32_t* prev, int prev_len,
+                  const gsv_sampling_params* sp, const float* noise, int step, int32_t* sampled,
+                  int32_t* argmax_tok, gsv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSV_H_ */

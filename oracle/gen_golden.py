@@ -25,44 +25,7 @@ from oracle import ref_import  # noqa: E402
 from oracle.t2s_oracle import T2SOracle  # noqa: E402
 
 
-# ---------------------------------------------------------------------------------
-# T2S cases: (name, config kwargs, batch spec, sampling)
-# ---------------------------------------------------------------------------------
-T2S_CASES = {
-    # reduced model, ragged batch, greedy, EOS reachable (vocab 65)
-    "t2s_small_greedy": dict(cfg=("small", dict(n_layer=2, dim=128, head=4, vocab=65, phoneme_vocab=48)), seed=3,
-                             x_lens=[9, 14, 6], P=7, top_k=1, top_p=1.0, temperature=1.0, rep=1.35,
-                             early_stop=40, shared_noise=False),
-    # reduced model, stochastic sampling with injected Exp(1) noise, top-k + top-p + temperature
-    "t2s_small_sample": dict(cfg=("small", dict(n_layer=2, dim=128, head=4, vocab=65, phoneme_vocab=48)), seed=5,
-                             x_lens=[11, 5, 8, 13], P=6, top_k=5, top_p=0.9, temperature=0.8, rep=1.35,
-                             early_stop=30, shared_noise=True),
-    # reduced model, top_k only (TTS.run defaults top_k=5, top_p=1)
-    "t2s_small_topk": dict(cfg=("small", dict(n_layer=3, dim=64, head=2, vocab=33, phoneme_vocab=48)), seed=7,
-                           x_lens=[10, 10], P=5, top_k=5, top_p=1.0, temperature=1.0, rep=1.35,
-                           early_stop=25, shared_noise=True),
-    # full v2 architecture, ragged B=2, greedy
-    "t2s_v2_greedy": dict(cfg=("v2", {}), seed=0, x_lens=[20, 13], P=12, top_k=1, top_p=1.0, temperature=1.0,
-                          rep=1.35, early_stop=24, shared_noise=False),
-}
-
-
-def t2s_case_inputs(case):
-    kind, kw = case["cfg"]
-    cfg = S.small_t2s_config(**kw) if kind == "small" else S.T2S_V2_CONFIG
-    m = cfg["model"]
-    sd = S.make_t2s_state_dict(cfg, seed=case["seed"])
-    xs = [torch.from_numpy(S.hash_ints(f"x{i}", n, m["phoneme_vocab_size"], case["seed"])).long()
-          for i, n in enumerate(case["x_lens"])]
-    berts = [S.hash_symmetric(f"bert{i}", (1024, n), 0.5, case["seed"]) for i, n in enumerate(case["x_lens"])]
-    prompt = torch.from_numpy(S.hash_ints("prompt", case["P"], m["vocab_size"] - 1, case["seed"])).long()
-    prompts = prompt.unsqueeze(0).expand(len(xs), -1).contiguous()
-    noise = None
-    if case["shared_noise"]:
-        u = S.hash_uniform("expnoise", 1500 * m["vocab_size"], case["seed"]).astype(np.float64)
-        noise = torch.from_numpy((-np.log1p(-u)).astype(np.float32).reshape(1500, 1, m["vocab_size"]))
-        noise = noise.clamp_min(1e-10)
-    return cfg, sd, xs, berts, prompts, noise
+from oracle.cases import T2S_CASES, t2s_case_inputs  # noqa: E402
 
 
 def run_reference_t2s(cfg, sd, xs, berts, prompts, noise, case, naive=False):

@@ -20,23 +20,7 @@ from oracle import ref_import  # noqa: E402
 from oracle.vits_oracle import VitsOracle  # noqa: E402
 from oracle import aa_oracle  # noqa: E402
 
-VITS_CASES = {
-    "vits_small": dict(cfg="small", seed=2, T=12, L=9, Tr=[30], noise_scale=0.5),
-    "vits_small_2ref": dict(cfg="small", seed=4, T=7, L=5, Tr=[24, 17], noise_scale=0.5),
-    "vits_v2": dict(cfg="v2", seed=0, T=10, L=8, Tr=[40], noise_scale=0.5),
-}
-
-
-def vits_case_inputs(case):
-    cfg = S.small_vits_config() if case["cfg"] == "small" else S.VITS_V2_CONFIG
-    sd = S.make_vits_state_dict(cfg, seed=case["seed"])
-    codes = torch.from_numpy(S.hash_ints("codes", case["T"], 1024, case["seed"])).view(1, 1, -1)
-    text = torch.from_numpy(S.hash_ints("text", case["L"], cfg["n_symbols"], case["seed"])).view(1, -1)
-    refers = [torch.from_numpy(S.hash_uniform(f"refer{i}", 1025 * tr, case["seed"]).reshape(1, 1025, tr).copy())
-              for i, tr in enumerate(case["Tr"])]
-    noise = S.hash_normal("vits_noise", (cfg["model"]["inter_channels"], 2 * case["T"]), case["seed"])
-    ssl = S.hash_symmetric("ssl", (1, 768, 2 * case["T"]), 1.0, case["seed"])
-    return cfg, sd, codes, text, refers, noise, ssl
+from oracle.cases import VITS_CASES, vits_case_inputs  # noqa: E402
 
 
 def build_reference_vits(cfg, sd):

@@ -1,0 +1,122 @@
+"""GPU: single kernels through the C ABI against plain torch fp32 references of the same op."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _conv(x_ct, w, bias, dtype, dil=1, stride=1, pre_lrelu=None, res=None, post=0, scale=1.0, accumulate=None):
+    """x_ct [Cin, T] fp32 cpu, w [Cout, Cin, k] -> y [Cout, T_out] via gsv_op_conv1d (channels-last inside)."""
+    from gsv import _lib
+    _lib.init(0)
+    Cout, Cin, k = w.shape
+    T = x_ct.shape[1]
+    pad = (k * dil - dil) // 2
+    T_out = (T + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    x = x_ct.t().contiguous().to(DEV, dtype)
+    wp = w.permute(0, 2, 1).reshape(Cout, k * Cin).contiguous().to(DEV, dtype)
+    y = torch.zeros(T_out, Cout, device=DEV, dtype=dtype) if accumulate is None else accumulate.t().contiguous().to(DEV, dtype)
+    b = bias.to(DEV, torch.float32).contiguous() if bias is not None else None
+    r = res.t().contiguous().to(DEV, dtype) if res is not None else None
+    d = _lib.ConvDesc(x.data_ptr(), wp.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(),
+                      r.data_ptr() if r is not None else None, T, T_out, Cin, Cout, k, stride, dil, pad,
+                      3 if pre_lrelu is not None else 0, pre_lrelu or 0.0, post, scale,
+                      1 if accumulate is not None else 0, 0, 0, 0)
+    _lib.check(_lib.lib().gsv_op_conv1d(C.byref(d), _lib.dtype_code(dtype), None))
+    torch.cuda.synchronize()
+    return y.float().cpu().t()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-2)])
+@pytest.mark.parametrize("Cin,Cout,k,dil,T", [(192, 512, 7, 1, 50), (256, 256, 11, 5, 333), (64, 64, 3, 3, 700),
+                                               (16, 16, 11, 1, 1000), (32, 32, 7, 5, 129), (768, 192, 1, 1, 37),
+                                               (96, 40, 3, 1, 65), (8, 24, 5, 1, 31)])
+def test_conv1d_matches_torch(dtype, tol, Cin, Cout, k, dil, T):
+    torch.manual_seed(Cin * 31 + k)
+    x = torch.randn(Cin, T)
+    w = torch.randn(Cout, Cin, k) / (Cin * k) ** 0.5
+    b = torch.randn(Cout)
+    res = torch.randn(Cout, T)
+    ref = F.conv1d(F.leaky_relu(x, 0.1).unsqueeze(0), w, b, padding=(k * dil - dil) // 2, dilation=dil)[0] + res
+    got = _conv(x, w, b, dtype, dil=dil, pre_lrelu=0.1, res=res)
+    assert (got - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+
+
+def test_conv1d_edges_stride_scale_accumulate_tanh():
+    torch.manual_seed(3)
+    x = torch.randn(24, 41)
+    w = torch.randn(16, 24, 2) / 7
+    ref = F.conv1d(x.unsqueeze(0), w, None, stride=2)[0]
+    from gsv import _lib
+    # stride-2, k=2, no padding (the ssl_proj shape of extract_latent)
+    _lib.init(0)
+    xd = x.t().contiguous().to(DEV)
+    wp = w.permute(0, 2, 1).reshape(16, 48).contiguous().to(DEV)
+    y = torch.zeros(20, 16, device=DEV)
+    d = _lib.ConvDesc(xd.data_ptr(), wp.data_ptr(), None, y.data_ptr(), None, 41, 20, 24, 16, 2, 2, 1, 0, 0, 0.0, 0,
+                      1.0, 0, 0, 0, 0)
+    _lib.check(_lib.lib().gsv_op_conv1d(C.byref(d), 0, None))
+    torch.cuda.synchronize()
+    assert (y.cpu().t() - ref).abs().max() < 1e-5
+    # scale + accumulate + tanh
+    x2 = torch.randn(32, 77)
+    w2 = torch.randn(32, 32, 3) / 10
+    prev = torch.randn(32, 77)
+    ref2 = prev + torch.tanh(F.conv1d(x2.unsqueeze(0), w2, None, padding=1)[0] / 3.0)
+    got2 = _conv(x2, w2, None, torch.float32, post=2, scale=1.0 / 3.0, accumulate=prev)
+    assert (got2 - ref2).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("u,k,Cin,Cout,T", [(10, 16, 64, 32, 23), (8, 16, 32, 16, 40), (2, 8, 128, 64, 33),
+                                             (2, 2, 64, 32, 50), (4, 8, 128, 64, 17)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-2)])
+def test_transposed_conv_as_polyphase_conv(u, k, Cin, Cout, T, dtype, tol):
+    """ConvTranspose1d(stride u, padding (k-u)/2) restated as a ceil(k/u)-tap conv producing u*Cout
+    virtual channels with a scatter epilogue (the generator's upsamplers, models.py:427-437)."""
+    from gsv import _lib
+    _lib.init(0)
+    torch.manual_seed(u * 7 + k)
+    x = torch.randn(Cin, T)
+    w = torch.randn(Cin, Cout, k) / (Cin * k / u) ** 0.5
+    b = torch.randn(Cout)
+    pad = (k - u) // 2
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1).unsqueeze(0), w, b, stride=u, padding=pad)[0]
+    taps = -(-k // u)
+    wv = torch.zeros(u * Cout, taps, Cin)
+    for p in range(u):
+        for q in range(taps):
+            j = q * u + p
+            if j < k:
+                wv[p * Cout:(p + 1) * Cout, q, :] = w[:, :, j].t()
+    xd = x.t().contiguous().to(DEV, dtype)
+    wd = wv.reshape(u * Cout, taps * Cin).contiguous().to(DEV, dtype)
+    bd = b.to(DEV)
+    T_out = T * u
+    y = torch.zeros(T_out, Cout, device=DEV, dtype=dtype)
+    d = _lib.ConvDesc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), None, T, T_out, Cin, u * Cout, taps, 1,
+                      -1, 0, 3, 0.1, 0, 1.0, 0, 0, u, pad)
+    _lib.check(_lib.lib().gsv_op_conv1d(C.byref(d), _lib.dtype_code(dtype), None))
+    torch.cuda.synchronize()
+    assert ref.shape[1] == T_out
+    assert (y.float().cpu().t() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+
+
+def test_layernorm_matches_torch():
+    from gsv import _lib
+    _lib.init(0)
+    torch.manual_seed(1)
+    for dtype, tol in [(torch.float32, 1e-5), (torch.float16, 4e-3)]:
+        x = torch.randn(37, 512)
+        r = torch.randn(37, 512)
+        g, b = torch.rand(512) + 0.5, torch.randn(512)
+        ref = F.layer_norm((x.to(dtype) + r.to(dtype)).float(), [512], g, b, 1e-5)
+        xd, rd = x.to(DEV, dtype), r.to(DEV, dtype)
+        y = torch.empty_like(xd)
+        _lib.check(_lib.lib().gsv_op_layernorm(xd.data_ptr(), rd.data_ptr(), g.to(DEV).data_ptr(), b.to(DEV).data_ptr(),
+                                               y.data_ptr(), 37, 512, 1e-5, _lib.dtype_code(dtype), None))
+        torch.cuda.synchronize()
+        assert (y.float().cpu() - ref).abs().max() < tol * 10
