@@ -114,9 +114,9 @@ def test_layernorm_matches_torch():
         r = torch.randn(37, 512)
         g, b = torch.rand(512) + 0.5, torch.randn(512)
         ref = F.layer_norm((x.to(dtype) + r.to(dtype)).float(), [512], g, b, 1e-5)
-        xd, rd = x.to(DEV, dtype), r.to(DEV, dtype)
+        xd, rd, gd, bd = x.to(DEV, dtype), r.to(DEV, dtype), g.to(DEV), b.to(DEV)
         y = torch.empty_like(xd)
-        _lib.check(_lib.lib().gsv_op_layernorm(xd.data_ptr(), rd.data_ptr(), g.to(DEV).data_ptr(), b.to(DEV).data_ptr(),
+        _lib.check(_lib.lib().gsv_op_layernorm(xd.data_ptr(), rd.data_ptr(), gd.data_ptr(), bd.data_ptr(),
                                                y.data_ptr(), 37, 512, 1e-5, _lib.dtype_code(dtype), None))
         torch.cuda.synchronize()
         assert (y.float().cpu() - ref).abs().max() < tol * 10
