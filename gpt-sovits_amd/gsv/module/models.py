@@ -1,0 +1,173 @@
+"""Host-side mirror of the reference's `SynthesizerTrn` inference interface
+(reference GPT_SoVITS/module/models.py:796-1010), backed by the HIP engine.
+
+`decode` and `extract_latent` keep the reference's argument meaning and return shapes.
+All arithmetic runs in libgsv_hip.so; there is no eager/PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+
+from .. import _lib
+
+
+class SynthesizerTrn:
+    def __init__(self, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads, n_layers,
+                 kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, n_speakers=0, gin_channels=0, use_sdp=True,
+                 semantic_frame_rate=None, freeze_quantizer=None, version="v2", device="cuda:0", dtype=torch.float16,
+                 n_symbols: Optional[int] = None, **kwargs):
+        if version not in ("v1", "v2"):
+            raise NotImplementedError(f"SoVITS {version}: only the v1/v2 decoder is in the hot-path scope this round")
+        if str(resblock) != "1":
+            raise NotImplementedError("only ResBlock1 generators (reference configs/s2.json)")
+        if semantic_frame_rate != "25hz":
+            raise NotImplementedError("only the 25hz semantic frame rate (reference configs/s2.json)")
+        self.version = version
+        self.spec_channels = spec_channels
+        self.inter_channels = inter_channels
+        self.hidden_channels = hidden_channels
+        self.upsample_rates = list(upsample_rates)
+        self.semantic_frame_rate = semantic_frame_rate
+        self.is_v2pro = False
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("gsv SynthesizerTrn runs on an MI355X (cuda/HIP device) only; there is no CPU path")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        self.dtype = dtype
+        if n_symbols is None:
+            n_symbols = 322 if version == "v1" else 732     # len(text/symbols.py) / len(text/symbols2.py)
+        cfg = _lib.VitsConfig()
+        cfg.inter_channels, cfg.hidden_channels, cfg.filter_channels = inter_channels, hidden_channels, filter_channels
+        cfg.n_heads, cfg.n_layers, cfg.kernel_size = n_heads, n_layers, kernel_size
+        cfg.gin_channels, cfg.n_symbols, cfg.ssl_dim, cfg.n_bins = gin_channels, n_symbols, 768, 1024
+        cfg.upsample_initial_channel = upsample_initial_channel
+        cfg.n_ups = len(upsample_rates)
+        for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
+            cfg.up_rates[i], cfg.up_kernels[i] = u, k
+        cfg.n_resblocks = len(resblock_kernel_sizes)
+        for j, (k, ds) in enumerate(zip(resblock_kernel_sizes, resblock_dilation_sizes)):
+            cfg.rb_kernels[j] = k
+            for c, d in enumerate(ds):
+                cfg.rb_dilations[j][c] = d
+        cfg.ref_bins = spec_channels if version == "v1" else 704
+        with torch.cuda.device(self.device):
+            _lib.init(idx)
+            h = C.c_void_p()
+            _lib.check(_lib.lib().gsv_vits_create(C.byref(cfg), _lib.dtype_code(dtype), C.byref(h)), "gsv_vits_create")
+            self._h = h
+            self.stream = torch.cuda.Stream(device=self.device)
+        self._loaded = False
+        self._ref_key = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().gsv_vits_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = False):
+        """Takes the reference checkpoint's `weight` dict (enc_q.* absent or ignored, as with the
+        reference's strict=False load, TTS.py:554).  Weight-norm pairs are folded in the library."""
+        if self._loaded:
+            raise RuntimeError("weights already loaded; create a new SynthesizerTrn")
+        l = _lib.lib()
+        with torch.cuda.device(self.device):
+            for k, v in state_dict.items():
+                if not torch.is_tensor(v) or k.startswith("enc_q."):
+                    continue
+                t = v.detach().to("cpu", torch.float32).contiguous()
+                if t.numel() == 0:
+                    continue
+                _lib.check(l.gsv_vits_load_tensor(self._h, k.encode(), t.data_ptr(), t.numel()), f"load {k}")
+            _lib.check(l.gsv_vits_finalize(self._h), "gsv_vits_finalize")
+        self._loaded = True
+        return self
+
+    # ---- reference audio -------------------------------------------------------------
+    def _set_refer(self, refer: Union[torch.Tensor, Sequence[torch.Tensor]]):
+        refs = list(refer) if isinstance(refer, (list, tuple)) else [refer]
+        key = tuple((r.data_ptr(), tuple(r.shape), r._version) for r in refs)
+        if key == self._ref_key:
+            return
+        keep = [r.to(self.device, torch.float32).contiguous() for r in refs]
+        ptrs = (C.c_void_p * len(keep))(*[r.data_ptr() for r in keep])
+        frames = (C.c_int * len(keep))(*[int(r.shape[2]) for r in keep])
+        bins = int(keep[0].shape[1])
+        _lib.check(_lib.lib().gsv_vits_set_refer(self._h, ptrs, frames, bins, len(keep),
+                                                 C.c_void_p(self.stream.cuda_stream)), "gsv_vits_set_refer")
+        self.stream.synchronize()
+        self._ref_key = key
+
+    @torch.no_grad()
+    def decode(self, codes: torch.Tensor, text: torch.Tensor, refer, noise_scale: float = 0.5, speed: float = 1,
+               sv_emb=None, noise: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
+        """reference models.py:961-1005: codes [1,1,T] int64, text [1,L] int64, refer = tensor or list of
+        [1, bins, Tr] spectrograms -> waveform [1, 1, 2T*prod(upsample_rates)].
+        `noise` (optional, [inter, 2T]) injects the randn_like draw of models.py:1000 for parity tests."""
+        if not self._loaded:
+            raise RuntimeError("load_state_dict() first")
+        if speed != 1:
+            raise NotImplementedError("speed != 1 (linear interpolation of enc_p output, models.py:226-228) "
+                                      "is not built yet")
+        if sv_emb is not None:
+            raise NotImplementedError("v2Pro speaker-verification conditioning is out of scope (SURVEY section 8f N4)")
+        if codes.numel() == 0 or text.numel() == 0:
+            raise ValueError("decode needs at least one semantic token and one phoneme")
+        T = int(codes.shape[-1])
+        L = int(text.shape[-1])
+        up = math.prod(self.upsample_rates)
+        with torch.cuda.device(self.device):
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._set_refer(refer)
+            cd = codes.reshape(-1).to(self.device, torch.int32).contiguous()
+            tx = text.reshape(-1).to(self.device, torch.int32).contiguous()
+            nz = None
+            if noise is not None:
+                nz = noise.reshape(self.inter_channels, 2 * T).to(self.device, torch.float32).contiguous()
+            wav = torch.empty(2 * T * up, dtype=torch.float32, device=self.device)
+            _lib.check(_lib.lib().gsv_vits_decode(self._h, cd.data_ptr(), T, tx.data_ptr(), L,
+                                                  nz.data_ptr() if nz is not None else None, float(noise_scale),
+                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, wav.data_ptr(),
+                                                  C.c_void_p(self.stream.cuda_stream)), "gsv_vits_decode")
+            self.stream.synchronize()
+        return wav.to(self.dtype).view(1, 1, -1)
+
+    @torch.no_grad()
+    def extract_latent(self, x: torch.Tensor) -> torch.Tensor:
+        """reference models.py:1007-1010: HuBERT features [1, 768, T50] -> codes [1, 1, T50 // 2] (int64)."""
+        if not self._loaded:
+            raise RuntimeError("load_state_dict() first")
+        T50 = int(x.shape[-1])
+        with torch.cuda.device(self.device):
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            xs = x.reshape(768, T50).to(self.device, torch.float32).contiguous()
+            n = (T50 - 2) // 2 + 1
+            out = torch.empty(n, dtype=torch.int32, device=self.device)
+            _lib.check(_lib.lib().gsv_vits_extract_latent(self._h, xs.data_ptr(), T50, out.data_ptr(),
+                                                          C.c_void_p(self.stream.cuda_stream)), "gsv_vits_extract_latent")
+            self.stream.synchronize()
+        return out.long().view(1, 1, -1)
+
+    # ---- test / bench hooks -------------------------------------------------------------
+    def debug_tensor(self, name: str, numel: int) -> torch.Tensor:
+        out = torch.empty(numel, dtype=torch.float32, device=self.device)
+        n = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().gsv_vits_debug_tensor(self._h, name.encode(), out.data_ptr(), numel, C.byref(n),
+                                                        C.c_void_p(self.stream.cuda_stream)))
+            self.stream.synchronize()
+        return out[: n.value]
+
+    def last_timing(self):
+        a, b = C.c_float(0), C.c_float(0)
+        _lib.check(_lib.lib().gsv_vits_last_timing(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,115 @@
+"""GPU: the HIP SoVITS decoder (through the C ABI) against the reference's golden waveforms and
+the oracle; BigVGAN anti-alias activation against its golden."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import cases
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _engine(cfg, sd, dtype):
+    from gsv.module.models import SynthesizerTrn
+    d = cfg["data"]
+    m = SynthesizerTrn(d["filter_length"] // 2 + 1, cfg["train"]["segment_size"] // d["hop_length"],
+                       n_speakers=d["n_speakers"], version="v2", device=DEV, dtype=dtype, n_symbols=cfg["n_symbols"],
+                       **cfg["model"])
+    m.load_state_dict(sd)
+    return m
+
+
+@pytest.mark.parametrize("name", ["vits_small", "vits_small_2ref", "vits_v2"])
+def test_fp32_waveform_matches_reference(name):
+    """fp32 engine vs the reference's waveform (golden), same injected noise: max-abs <= 1e-4
+    (tolerance stated in BASELINE.md section 3); intermediates ge / m_p / z within 1e-4."""
+    case = cases.VITS_CASES[name]
+    cfg, sd, codes, text, refers, noise, ssl = cases.vits_case_inputs(case)
+    g = load_golden(name)
+    eng = _engine(cfg, sd, torch.float32)
+    wav = eng.decode(codes.to(DEV), text.to(DEV), [r.to(DEV) for r in refers], noise_scale=case["noise_scale"],
+                     noise=noise)
+    assert tuple(wav.shape) == g["wav"].shape
+    IC, F = cfg["model"]["inter_channels"], 2 * case["T"]
+    ge = eng.debug_tensor("ge", 512).cpu().numpy()
+    assert np.abs(ge - g["ge"].reshape(-1)).max() < 1e-4
+    m_p = eng.debug_tensor("m_p", IC * F).cpu().numpy().reshape(IC, F)
+    assert np.abs(m_p - g["m_p"]).max() < 2e-4
+    z = eng.debug_tensor("z", IC * F).cpu().numpy().reshape(IC, F)
+    assert np.abs(z - g["z"]).max() < 5e-4
+    assert np.abs(wav.float().cpu().numpy() - g["wav"]).max() <= 1e-4
+    lat = eng.extract_latent(ssl.to(DEV))
+    assert lat.cpu().numpy().tolist() == g["latent_codes"].tolist()      # integer codes: bit-exact
+
+
+@pytest.mark.parametrize("name", ["vits_small", "vits_v2"])
+def test_fp16_waveform_within_tolerance(name):
+    """fp16 engine (production dtype) vs the fp32 reference waveform: max-abs <= 2e-2 and
+    relative RMS error <= 3 % (fp16 storage of activations through ~100 conv layers)."""
+    case = cases.VITS_CASES[name]
+    cfg, sd, codes, text, refers, noise, ssl = cases.vits_case_inputs(case)
+    g = load_golden(name)
+    eng = _engine(cfg, sd, torch.float16)
+    wav = eng.decode(codes.to(DEV), text.to(DEV), [r.to(DEV) for r in refers], noise_scale=case["noise_scale"],
+                     noise=noise).float().cpu().numpy()
+    err = wav - g["wav"]
+    assert np.abs(err).max() <= 2e-2
+    assert np.sqrt((err ** 2).mean()) <= 0.03 * np.sqrt((g["wav"] ** 2).mean())
+
+
+def test_decode_edge_cases_and_determinism():
+    case = cases.VITS_CASES["vits_small"]
+    cfg, sd, codes, text, refers, noise, ssl = cases.vits_case_inputs(case)
+    eng = _engine(cfg, sd, torch.float32)
+    # single token / single phoneme (shortest legal input)
+    w1 = eng.decode(codes[:, :, :1].to(DEV), text[:, :1].to(DEV), refers[0].to(DEV), noise=noise[:, :2])
+    assert w1.shape == (1, 1, 2 * 16) and torch.isfinite(w1).all()
+    # empty inputs are rejected loudly
+    with pytest.raises(ValueError):
+        eng.decode(codes[:, :, :0].to(DEV), text.to(DEV), refers[0].to(DEV))
+    # counter-RNG noise: same seed -> same waveform, different seed -> different
+    a = eng.decode(codes.to(DEV), text.to(DEV), refers[0].to(DEV), seed=3)
+    b = eng.decode(codes.to(DEV), text.to(DEV), refers[0].to(DEV), seed=3)
+    c = eng.decode(codes.to(DEV), text.to(DEV), refers[0].to(DEV), seed=4)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    # time-axis concatenation property used by TTS.run (TTS.py:1259-1282): output length is
+    # tokens * 2 * prod(upsample_rates)
+    assert a.shape[-1] == case["T"] * 2 * 16
+
+
+@pytest.mark.parametrize("kind", ["snake", "snakebeta"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 1e-3)])
+def test_aa_activation_matches_reference_torch_path(kind, dtype, tol):
+    """the reference's own criterion for its CUDA kernel is mean-abs <= 1e-3 vs the torch path
+    (BigVGAN/tests/test_activation.py:41); golden = the reference torch path on rand(10,10,200)."""
+    from gsv.BigVGAN.alias_free_activation.cuda import anti_alias_activation as aa
+    from gsv import synthetic as S
+    g = load_golden("aa_" + kind)
+    C_, T, B = 10, 200, 10
+    x = torch.from_numpy(S.hash_uniform("aa_x_" + kind, B * C_ * T, 1).reshape(B, C_, T).copy())
+    la = S.hash_symmetric("aa_alpha_" + kind, (C_,), 0.5, 1)
+    lb = S.hash_symmetric("aa_beta_" + kind, (C_,), 0.5, 1) if kind == "snakebeta" else la
+    uf = torch.from_numpy(g["up_filter"]).view(1, 1, 12)
+    df = torch.from_numpy(g["down_filter"]).view(1, 1, 12)
+    out = aa.forward(x.to(DEV, dtype), uf.to(DEV, dtype), df.to(DEV, dtype), la.to(DEV, dtype), lb.to(DEV, dtype))
+    err = (out.float().cpu().numpy() - g["out"])
+    assert np.abs(err).mean() <= tol
+    assert np.abs(err).max() <= tol * 20
+
+
+def test_aa_activation_shapes_and_edges():
+    from gsv.BigVGAN.alias_free_activation.cuda import anti_alias_activation as aa
+    from oracle import aa_oracle
+    uf, df = aa_oracle.default_filters()
+    for (B, C_, T) in [(1, 3, 1), (2, 5, 7), (1, 2, 2048), (1, 2, 2049), (3, 4, 5000)]:
+        torch.manual_seed(T)
+        x = torch.randn(B, C_, T)
+        la, lb = torch.randn(C_) * 0.3, torch.randn(C_) * 0.3
+        ref = aa_oracle.aa_activation(x, la, lb, uf, df)
+        out = aa.forward(x.to(DEV), uf.view(1, 1, 12).to(DEV), df.view(1, 1, 12).to(DEV), la.to(DEV), lb.to(DEV))
+        assert (out.cpu() - ref).abs().max() < 2e-5
+    empty = aa.forward(torch.zeros(2, 3, 0, device=DEV), uf.view(1, 1, 12).to(DEV), df.view(1, 1, 12).to(DEV),
+                       torch.zeros(3, device=DEV), torch.zeros(3, device=DEV))
+    assert empty.shape == (2, 3, 0)
