@@ -189,11 +189,15 @@ __device__ __forceinline__ void mma16(f4v& acc, const f4& a, const f4& b) {
   for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
 }
 
-template <typename T, int CB, int NW, bool LNPRO>
+template <typename T, int CB, int NW, int KSL, int KV4>
 __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
+  // KSL = K / NW (k-slice per wave, compile time so every load is issued up front);
+  // KV4 > 0: LayerNorm prologue with K = 32*KV4, 8 threads per row, the row held in registers.
   typedef typename Frag16<T>::type F;
   constexpr int G = DT<T>::G;
   constexpr int KS = Frag16<T>::KS;  // k per MFMA group step
+  constexpr int NKS = KSL / KS;
+  constexpr bool LNPRO = KV4 > 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 16;
@@ -202,33 +206,68 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
   T* xs = (T*)smem;
   float* red = (float*)(smem + (LNPRO ? (size_t)CB * 16 * ldx * sizeof(T) : 0));
 
+  const int rowl = lane & 15, kg = lane >> 4;
+  const int kbeg = wave * KSL;
+  const bool wok = (n0 + rowl) < a.N;
+  const T* wrow = (const T*)a.w + (long long)(wok ? n0 + rowl : 0) * K + kbeg + G * kg;
+  // weight stream first: its HBM latency overlaps the LayerNorm prologue
+  F af[NKS];
+#pragma unroll
+  for (int i = 0; i < NKS; ++i) {
+    if (wok) af[i] = *(const F*)(wrow + i * KS);
+    else {
+#pragma unroll
+      for (int e = 0; e < G; ++e) af[i][e] = 0;
+    }
+  }
+
   if (LNPRO) {
-    // one wave per row: two-pass LayerNorm in fp32 (reference F.layer_norm, eps 1e-5)
-    for (int row = wave; row < CB * 16; row += NW) {
-      T* dst = xs + (long long)row * ldx;
-      if (row >= a.B) {
-        for (int c = lane; c < K; c += 64) dst[c] = (T)0.f;
-        continue;
+    constexpr int TPR = 8;                       // threads per row
+    constexpr int RPP = NW * 64 / TPR;           // rows per pass
+    constexpr int NV = KV4 > 0 ? KV4 : 1;
+    const int sub = tid & (TPR - 1);
+    f4 gm[NV], bt[NV];
+    if (a.gamma) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        gm[j] = *(const f4*)(a.gamma + (j * TPR + sub) * 4);
+        bt[j] = *(const f4*)(a.beta + (j * TPR + sub) * 4);
       }
-      const float* src = a.yin + (long long)row * K;
+    }
+    for (int r0 = 0; r0 < CB * 16; r0 += RPP) {
+      const int row = r0 + tid / TPR;
+      if (row >= CB * 16) break;
+      const bool live = row < a.B;
+      f4 v[NV];
+      const float* src = a.yin + (long long)(live ? row : 0) * K;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = live ? *(const f4*)(src + (j * TPR + sub) * 4) : (f4){0.f, 0.f, 0.f, 0.f};
       if (a.gamma) {
         float s = 0.f;
-        for (int c = lane; c < K; c += 64) s += src[c];
-        const float mean = wave_sum(s) / (float)K;
-        float v = 0.f;
-        for (int c = lane; c < K; c += 64) { float dlt = src[c] - mean; v += dlt * dlt; }
-        const float rstd = rsqrtf(wave_sum(v) / (float)K + 1e-5f);
-        for (int c = lane; c < K; c += 64) {
-          float o = (src[c] - mean) * rstd * a.gamma[c] + a.beta[c];
-          dst[c] = (T)o;
-          if (a.xres_out && blockIdx.x == 0) a.xres_out[(long long)row * K + c] = o;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        const float mean = s / (float)K;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { float dl = v[j][e] - mean; q += dl * dl; }
         }
-      } else {
-        for (int c = lane; c < K; c += 64) {
-          float o = src[c];
-          dst[c] = (T)o;
-          if (a.xres_out && blockIdx.x == 0) a.xres_out[(long long)row * K + c] = o;
+        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+        const float rstd = rsqrtf(q / (float)K + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] = live ? (v[j][e] - mean) * rstd * gm[j][e] + bt[j][e] : 0.f;
         }
+      }
+      T* dst = xs + (long long)row * ldx;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        typedef T T4 __attribute__((ext_vector_type(4)));
+        *(T4*)(dst + (j * TPR + sub) * 4) = (T4){(T)v[j][0], (T)v[j][1], (T)v[j][2], (T)v[j][3]};
+        if (a.xres_out && blockIdx.x == 0 && live) *(f4*)(a.xres_out + (long long)row * K + (j * TPR + sub) * 4) = v[j];
       }
     }
     __syncthreads();
@@ -237,38 +276,26 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
   f4v acc[CB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) acc[cb] = (f4v){0.f, 0.f, 0.f, 0.f};
-
-  const int rowl = lane & 15, kg = lane >> 4;
-  const int kslice = K / NW;
-  const int kbeg = wave * kslice;
-  const bool wok = (n0 + rowl) < a.N;
-  const T* wrow = (const T*)a.w + (long long)(wok ? n0 + rowl : 0) * K;
   const T* xg = (const T*)a.xin;
-#pragma unroll 4
-  for (int k0 = kbeg; k0 < kbeg + kslice; k0 += KS) {
-    const int k = k0 + G * kg;
-    F af;
-    if (wok) af = *(const F*)(wrow + k);
-    else {
+  F bf[NKS][CB];
 #pragma unroll
-      for (int i = 0; i < G; ++i) af[i] = 0;
-    }
+  for (int i = 0; i < NKS; ++i) {
+    const int k = kbeg + i * KS + G * kg;
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
-      F bf;
       const int brow = cb * 16 + rowl;
-      if (LNPRO) {
-        bf = *(const F*)(xs + (long long)brow * ldx + k);
-      } else {
-        if (brow < a.B) bf = *(const F*)(xg + (long long)brow * K + k);
-        else {
+      if (LNPRO) bf[i][cb] = *(const F*)(xs + (long long)brow * ldx + k);
+      else if (brow < a.B) bf[i][cb] = *(const F*)(xg + (long long)brow * K + k);
+      else {
 #pragma unroll
-          for (int i = 0; i < G; ++i) bf[i] = 0;
-        }
+        for (int e = 0; e < G; ++e) bf[i][cb][e] = 0;
       }
-      mma16(acc[cb], af, bf);
     }
   }
+#pragma unroll
+  for (int i = 0; i < NKS; ++i)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) mma16(acc[cb], af[i], bf[i][cb]);
   // combine the NW partial tiles through LDS (fixed summation order: deterministic)
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) *(f4v*)(red + ((wave * CB + cb) * 64 + lane) * 4) = acc[cb];
@@ -688,44 +715,50 @@ const std::vector<float>* find(gsv_t2s* h, const std::string& k, size_t n) {
   return &it->second;
 }
 
-template <typename T, int CB, int NW, bool LNPRO>
+template <typename T, int CB, int NW, int KSL, int KV4>
 int launch_dec_gemm_inst(const DecGemmArgs& a, hipStream_t s) {
   constexpr int G = DT<T>::G;
   size_t lds = (size_t)NW * CB * 64 * 16;
-  if (LNPRO) lds += (size_t)CB * 16 * (a.K + G) * sizeof(T);
-  auto kern = dec_gemm_kernel<T, CB, NW, LNPRO>;
+  if (KV4 > 0) lds += (size_t)CB * 16 * (a.K + G) * sizeof(T);
+  auto kern = dec_gemm_kernel<T, CB, NW, KSL, KV4>;
   if (lds > 64 * 1024) GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(cdiv(a.N, 16)), dim3(NW * 64), lds, s, a);
   GSV_HIP(hipGetLastError());
   return GSV_OK;
 }
 
-template <typename T, int CB, bool LNPRO>
-int launch_dec_gemm_nw(const DecGemmArgs& a, hipStream_t s) {
-  constexpr int KS = Frag16<T>::KS;
-  // waves per workgroup: split K so that each wave keeps >= 4 k-steps when possible
-  int nw = 16;
-  while (nw > 1 && (a.K % (nw * KS) != 0 || a.K / nw < 4 * KS)) nw >>= 1;
-  if (a.K % (nw * KS) != 0) { set_error("dec_gemm: K=%d not a multiple of %d", a.K, KS); return GSV_ERR_ARG; }
-  switch (nw) {
-    case 16: return launch_dec_gemm_inst<T, CB, 16, LNPRO>(a, s);
-    case 8: return launch_dec_gemm_inst<T, CB, 8, LNPRO>(a, s);
-    case 4: return launch_dec_gemm_inst<T, CB, 4, LNPRO>(a, s);
-    case 2: return launch_dec_gemm_inst<T, CB, 2, LNPRO>(a, s);
-    default: return launch_dec_gemm_inst<T, CB, 1, LNPRO>(a, s);
+// K = NW * KSL with KSL = 128 (64 for the 64-wide test model); LayerNorm prologue needs K = 32*KV4
+template <typename T, int CB>
+int launch_dec_gemm_cb(const DecGemmArgs& a, bool lnpro, hipStream_t s) {
+  const int K = a.K;
+#define GSV_DG_CASE(NWV, KSLV, KV4V) return launch_dec_gemm_inst<T, CB, NWV, KSLV, KV4V>(a, s)
+  if (lnpro) {
+    if (K == 512) GSV_DG_CASE(4, 128, 16);
+    if (K == 256) GSV_DG_CASE(2, 128, 8);
+    if (K == 128) GSV_DG_CASE(1, 128, 4);
+    if (K == 64) GSV_DG_CASE(1, 64, 2);
+    if (K == 1024) GSV_DG_CASE(8, 128, 32);
+  } else {
+    if (K == 2048) GSV_DG_CASE(16, 128, 0);
+    if (K == 1024) GSV_DG_CASE(8, 128, 0);
+    if (K == 512) GSV_DG_CASE(4, 128, 0);
+    if (K == 256) GSV_DG_CASE(2, 128, 0);
+    if (K == 128) GSV_DG_CASE(1, 128, 0);
+    if (K == 64) GSV_DG_CASE(1, 64, 0);
+    if (K == 4096) GSV_DG_CASE(16, 256, 0);
   }
+#undef GSV_DG_CASE
+  set_error("dec_gemm: unsupported contraction length K=%d (lnpro=%d)", K, (int)lnpro);
+  return GSV_ERR_ARG;
 }
 
 template <typename T>
 int launch_dec_gemm(const DecGemmArgs& a, bool lnpro, hipStream_t s) {
   const int cb = cdiv(a.B, 16);
-#define GSV_DG(CBV)                                                        \
-  return lnpro ? launch_dec_gemm_nw<T, CBV, true>(a, s) : launch_dec_gemm_nw<T, CBV, false>(a, s)
-  if (cb <= 1) { GSV_DG(1); }
-  if (cb <= 2) { GSV_DG(2); }
-  if (cb <= 4) { GSV_DG(4); }
-  if (cb <= 8) { GSV_DG(8); }
-#undef GSV_DG
+  if (cb <= 1) return launch_dec_gemm_cb<T, 1>(a, lnpro, s);
+  if (cb <= 2) return launch_dec_gemm_cb<T, 2>(a, lnpro, s);
+  if (cb <= 4) return launch_dec_gemm_cb<T, 4>(a, lnpro, s);
+  if (cb <= 8) return launch_dec_gemm_cb<T, 8>(a, lnpro, s);
   set_error("dec_gemm: batch %d too large", a.B);
   return GSV_ERR_ARG;
 }
@@ -739,7 +772,8 @@ extern "C" {
 int gsv_t2s_create(const gsv_t2s_config* cfg, int dtype, int max_batch, int max_seq, gsv_t2s_t** out) {
   GSV_REQUIRE(cfg && out, "t2s_create: null argument");
   GSV_REQUIRE(dtype == GSV_F16 || dtype == GSV_F32, "t2s_create: bad dtype");
-  GSV_REQUIRE(cfg->dim % 64 == 0 && cfg->dim % cfg->n_head == 0, "t2s_create: dim must be a multiple of 64 and of n_head");
+  GSV_REQUIRE((cfg->dim == 64 || cfg->dim == 128 || cfg->dim == 256 || cfg->dim == 512 || cfg->dim == 1024) && cfg->ffn_dim == 4 * cfg->dim,
+              "t2s_create: dim must be 64/128/256/512/1024 with ffn_dim = 4*dim (got %d, %d)", cfg->dim, cfg->ffn_dim);
   GSV_REQUIRE(cfg->dim / cfg->n_head == 32, "t2s_create: head_dim must be 32 (got %d)", cfg->dim / cfg->n_head);
   GSV_REQUIRE(cfg->vocab <= 2048, "t2s_create: vocab %d > 2048", cfg->vocab);
   GSV_REQUIRE(max_batch >= 1 && max_batch <= (dtype == GSV_F16 ? 128 : 64), "t2s_create: max_batch %d out of range", max_batch);
@@ -865,7 +899,7 @@ static int launch_tail(gsv_t2s* h, hipStream_t s) {
 }
 
 template <typename T>
-static int launch_decode_layers(gsv_t2s* h, hipStream_t s, int only_attn) {
+static int launch_decode_layers(gsv_t2s* h, hipStream_t s, int only_attn, hipEvent_t* attn_ev = nullptr) {
   const auto& c = h->cfg;
   const int d = c.dim, H = c.n_head;
   for (int li = 0; li < c.n_layer; ++li) {
@@ -881,9 +915,11 @@ static int launch_decode_layers(gsv_t2s* h, hipStream_t s, int only_attn) {
       a.d = d; a.H = H; a.smax = h->max_seq;
       GSV_RC(launch_dec_gemm<T>(a, true, s));
     }
+    if (attn_ev) GSV_HIP(hipEventRecord(attn_ev[2 * li], s));
     hipLaunchKernelGGL((decode_attn_kernel<T, 32>), dim3(H, h->B), dim3(256), 0, s, (const T*)h->qbuf,
                        (const T*)kv_ptr(h, li, 0), (const T*)kv_ptr(h, li, 1), h->d_kv_len, h->d_active, H, h->max_seq,
                        (T*)h->abuf);
+    if (attn_ev) GSV_HIP(hipEventRecord(attn_ev[2 * li + 1], s));
     if (only_attn) continue;
     {
       DecGemmArgs a;
@@ -1105,27 +1141,43 @@ int64_t gsv_t2s_step_bytes(gsv_t2s_t* h, int64_t* attn_bytes) {
 }
 
 int gsv_t2s_time_step(gsv_t2s_t* h, int iters, float* step_ms, float* attn_ms, gsv_stream_t stream) {
+  // In-situ timing of the decode step at the current cache state: the full per-layer kernel
+  // sequence (QKV+append, attention, out-proj, FFN1, FFN2) is launched eagerly on `stream` with a
+  // HIP event pair around every decode-attention launch, so each attention launch runs behind its
+  // producer and in front of its consumer exactly as in the replayed graph.  Rows are forced
+  // active for the measurement (finished rows skip attention) and restored afterwards; no row
+  // state advances because the sampling tail is not launched.
   GSV_REQUIRE(h && h->finalized && h->B > 0 && iters > 0, "t2s_time_step: bad state");
   hipStream_t s = (hipStream_t)stream;
-  hipEvent_t e0, e1;
-  GSV_HIP(hipEventCreate(&e0));
-  GSV_HIP(hipEventCreate(&e1));
-  // attention kernel alone: 24 layers' caches back to back (472 MB at B=32,S=300 > Infinity Cache,
-  // so every launch streams from HBM)
+  const int L = h->cfg.n_layer, B = h->B;
+  std::vector<int> saved(B), ones(B, 1);
+  GSV_HIP(hipMemcpy(saved.data(), h->d_active, B * 4, hipMemcpyDeviceToHost));
+  GSV_HIP(hipMemcpy(h->d_active, ones.data(), B * 4, hipMemcpyHostToDevice));
+  std::vector<hipEvent_t> ev((size_t)iters * 2 * L + 2);
+  for (auto& e : ev) GSV_HIP(hipEventCreate(&e));
   int rc = GSV_OK;
   for (int w = 0; w < 2 && !rc; ++w)
-    rc = h->dtype == GSV_F16 ? launch_decode_layers<_Float16>(h, s, 1) : launch_decode_layers<float>(h, s, 1);
-  GSV_HIP(hipEventRecord(e0, s));
+    rc = h->dtype == GSV_F16 ? launch_decode_layers<_Float16>(h, s, 0) : launch_decode_layers<float>(h, s, 0);
+  GSV_HIP(hipEventRecord(ev[(size_t)iters * 2 * L], s));
   for (int i = 0; i < iters && !rc; ++i)
-    rc = h->dtype == GSV_F16 ? launch_decode_layers<_Float16>(h, s, 1) : launch_decode_layers<float>(h, s, 1);
-  GSV_HIP(hipEventRecord(e1, s));
-  GSV_HIP(hipEventSynchronize(e1));
-  float ms = 0.f;
-  GSV_HIP(hipEventElapsedTime(&ms, e0, e1));
-  if (attn_ms) *attn_ms = ms / (float)(iters * h->cfg.n_layer);
-  if (step_ms) *step_ms = 0.f;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+    rc = h->dtype == GSV_F16 ? launch_decode_layers<_Float16>(h, s, 0, ev.data() + (size_t)i * 2 * L)
+                             : launch_decode_layers<float>(h, s, 0, ev.data() + (size_t)i * 2 * L);
+  GSV_HIP(hipEventRecord(ev[(size_t)iters * 2 * L + 1], s));
+  GSV_HIP(hipStreamSynchronize(s));
+  GSV_HIP(hipMemcpy(h->d_active, saved.data(), B * 4, hipMemcpyHostToDevice));
+  if (!rc) {
+    double tot = 0.0;
+    for (int i = 0; i < iters * L; ++i) {
+      float ms = 0.f;
+      GSV_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+      tot += ms;
+    }
+    if (attn_ms) *attn_ms = (float)(tot / (iters * L));
+    float ms = 0.f;
+    GSV_HIP(hipEventElapsedTime(&ms, ev[(size_t)iters * 2 * L], ev[(size_t)iters * 2 * L + 1]));
+    if (step_ms) *step_ms = ms / iters;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
 }
 

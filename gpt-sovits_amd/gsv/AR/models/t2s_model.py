@@ -213,7 +213,9 @@ class Text2SemanticDecoder:
         return out
 
     def time_attention(self, iters: int = 20):
-        """(avg ms per decode-attention launch, algorithmic HBM bytes per launch) at the current cache state."""
+        """(avg ms per decode-attention launch, algorithmic HBM bytes per launch, algorithmic bytes of a
+        whole decode step, eager ms of one step's 24-layer kernel sequence) at the current cache state,
+        measured in situ with HIP events on the engine stream (gsv_t2s_time_step)."""
         ms = C.c_float(0)
         step = C.c_float(0)
         ab = C.c_int64(0)
@@ -221,4 +223,4 @@ class Text2SemanticDecoder:
             l = _lib.lib()
             _lib.check(l.gsv_t2s_time_step(self._h, iters, C.byref(step), C.byref(ms), C.c_void_p(self.stream.cuda_stream)))
             total = l.gsv_t2s_step_bytes(self._h, C.byref(ab))
-        return ms.value, ab.value, total
+        return ms.value, ab.value, total, step.value

@@ -1,0 +1,361 @@
+"""Host-side mirror of the reference pipeline API `TTS_infer_pack.TTS` (reference
+GPT_SoVITS/TTS_infer_pack/TTS.py: `TTS_Config`:217, `TTS`:412, `run`:984, `to_batch`:842,
+`recovery_order`:957, `audio_postprocess`:1377), v1/v2 path, on the HIP engines.
+
+What is kept: the `run(inputs) -> generator of (sr, int16 ndarray)` contract with the reference's
+keys and defaults, length-bucketed batching, AR -> one time-axis-concatenated `decode` per batch,
+per-fragment peak normalisation, fragment silence, original-order recovery, x32768 int16 scaling,
+the error protocol (1 s of silence then re-raise) and `stop()`.
+
+What is *not* here (out of scope this round): the text front-end (G2P/BERT) and the
+reference-audio front-end (HuBERT, STFT).  `run` therefore takes either a pluggable
+`text_frontend` callable or pre-tokenised segments (`inputs["segments"]`), and the prompt is set
+with `set_prompt_cache(prompt_semantic, refer_spec, phones, bert)` instead of a wav path.
+"""
+from __future__ import annotations
+
+import math
+import os
+import random
+import time
+import traceback
+from typing import Callable, Dict, Generator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from ..AR.models.t2s_model import Text2SemanticDecoder
+from ..module.models import SynthesizerTrn
+
+
+class NO_PROMPT_ERROR(Exception):
+    pass
+
+
+def set_seed(seed: int) -> int:
+    """reference TTS.py:180-205: -1 -> random seed; seeds python/numpy/torch."""
+    seed = int(seed)
+    seed = seed if seed != -1 else random.randint(0, 2 ** 32 - 1)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    return seed
+
+
+class TTS_Config:
+    """Subset of the reference's TTS_Config (TTS.py:217-410) the hot path reads.  `configs` is a dict
+    with the reference's keys (device, is_half, version, t2s_weights_path, vits_weights_path); weight
+    paths may also be replaced by in-memory checkpoints via TTS.init_*_weights(state=...)."""
+    v1_languages = ["auto", "auto_yue", "en", "zh", "ja", "all_zh", "all_ja"]
+    v2_languages = ["auto", "auto_yue", "en", "zh", "ja", "yue", "ko", "all_zh", "all_ja", "all_yue", "all_ko"]
+
+    def __init__(self, configs: Optional[dict] = None):
+        configs = dict(configs or {})
+        if "custom" in configs:
+            configs = dict(configs["custom"])
+        self.device = torch.device(configs.get("device", "cuda:0"))
+        self.is_half = bool(configs.get("is_half", True))
+        self.version = configs.get("version", "v2")
+        if self.version not in ("v1", "v2"):
+            raise NotImplementedError(f"version {self.version}: the v1/v2 pipeline is the scope of this build")
+        self.t2s_weights_path = configs.get("t2s_weights_path")
+        self.vits_weights_path = configs.get("vits_weights_path")
+        self.max_batch = int(configs.get("max_batch", 32))
+        self.max_seq = int(configs.get("max_seq", 2048))
+        self.use_vocoder = False
+        self.max_sec = None
+        self.hz: int = 50
+        self.semantic_frame_rate: str = "25hz"
+        self.segment_size: int = 20480
+        self.filter_length: int = 2048
+        self.sampling_rate: int = 32000
+        self.hop_length: int = 640
+        self.win_length: int = 2048
+        self.n_speakers: int = 300
+        self.languages = self.v1_languages if self.version == "v1" else self.v2_languages
+
+    @property
+    def precision(self):
+        return torch.float16 if self.is_half else torch.float32
+
+
+class TTS:
+    def __init__(self, configs=None):
+        self.configs = configs if isinstance(configs, TTS_Config) else TTS_Config(configs)
+        self.t2s_model: Optional[Text2SemanticDecoder] = None
+        self.vits_model: Optional[SynthesizerTrn] = None
+        self.text_frontend: Optional[Callable] = None
+        self.prompt_cache: dict = {
+            "ref_audio_path": None, "prompt_semantic": None, "refer_spec": [], "prompt_text": None,
+            "prompt_lang": None, "phones": None, "bert_features": None, "norm_text": None, "aux_ref_audio_paths": [],
+        }
+        self.stop_flag = False
+        self.precision = self.configs.precision
+        self._t2s_state = None
+        self._vits_state = None
+
+    # ---- weights (reference TTS.py:484-603) ------------------------------------------------
+    def init_t2s_weights(self, weights_path: Optional[str] = None, state: Optional[dict] = None):
+        """`state` = {"weight": state_dict, "config": {...}} as stored in the reference's .ckpt
+        (TTS.py:590-594); `weights_path` loads such a file with a non-executing loader."""
+        if state is None:
+            state = torch.load(weights_path, map_location="cpu", weights_only=True)
+        self._t2s_state = state
+        config = state["config"]
+        self.configs.max_sec = config["data"]["max_sec"]
+        self.configs.t2s_weights_path = weights_path
+        m = Text2SemanticDecoder(config, device=self.configs.device, dtype=self.precision,
+                                 max_batch=self.configs.max_batch, max_seq=self.configs.max_seq)
+        m.load_state_dict(state["weight"])
+        self.t2s_model = m
+
+    def init_vits_weights(self, weights_path: Optional[str] = None, state: Optional[dict] = None):
+        if state is None:
+            state = load_sovits_new(weights_path)
+        self._vits_state = state
+        hps = state["config"]
+        d, mcfg = hps["data"], dict(hps["model"])
+        mcfg.pop("version", None)
+        self.configs.filter_length = d["filter_length"]
+        self.configs.segment_size = hps["train"]["segment_size"]
+        self.configs.sampling_rate = d["sampling_rate"]
+        self.configs.hop_length = d["hop_length"]
+        self.configs.win_length = d["win_length"]
+        self.configs.n_speakers = d["n_speakers"]
+        self.configs.vits_weights_path = weights_path
+        v = SynthesizerTrn(d["filter_length"] // 2 + 1, hps["train"]["segment_size"] // d["hop_length"],
+                           n_speakers=d["n_speakers"], version=self.configs.version, device=self.configs.device,
+                           dtype=self.precision, n_symbols=hps.get("n_symbols"), **mcfg)
+        v.load_state_dict(state["weight"])
+        self.vits_model = v
+
+    # ---- prompt cache (replaces set_ref_audio's HuBERT/STFT front-end, TTS.py:737-819) ---------
+    def set_prompt_cache(self, prompt_semantic: torch.Tensor, refer_spec: Sequence[torch.Tensor],
+                         phones: Optional[List[int]] = None, bert_features: Optional[torch.Tensor] = None,
+                         norm_text: str = ""):
+        self.prompt_cache["prompt_semantic"] = prompt_semantic.to(self.configs.device)
+        self.prompt_cache["refer_spec"] = [(s, None) for s in refer_spec]
+        self.prompt_cache["phones"] = phones
+        self.prompt_cache["bert_features"] = bert_features
+        self.prompt_cache["norm_text"] = norm_text
+
+    def stop(self):
+        self.stop_flag = True
+
+    # ---- batching (reference TTS.py:842-973) ------------------------------------------------
+    def to_batch(self, data: list, prompt_data: Optional[dict] = None, batch_size: int = 5, threshold: float = 0.75,
+                 split_bucket: bool = True, device=torch.device("cpu"), precision=torch.float32):
+        """Length-sorted bucketing: a candidate bucket [pos, pos_end) is accepted when its median /
+        mean text length ratio reaches `threshold` (or it is a single item), otherwise it shrinks from
+        the long end (TTS.py:859-879).  Items then get prompt phones / bert prepended (:899-904)."""
+        lens = [len(it["norm_text"]) for it in data]
+        batch_index_list: List[List[int]] = []
+        if split_bucket:
+            order = sorted(range(len(data)), key=lambda i: lens[i])       # stable, like list.sort
+            sl = np.array([lens[i] for i in order], dtype=np.float32)
+            pos = 0
+            while pos < len(order):
+                end = min(pos + batch_size, len(order))
+                while True:
+                    seg = sl[pos:end]
+                    score = seg[(end - pos) // 2] / (seg.mean() + 1e-8)
+                    if score >= threshold or end - pos == 1:
+                        break
+                    end -= 1
+                batch_index_list.append([order[i] for i in range(pos, end)])
+                pos = end
+            assert sum(len(b) for b in batch_index_list) == len(data)
+        else:
+            for i in range(len(data)):
+                if i % batch_size == 0:
+                    batch_index_list.append([])
+                batch_index_list[-1].append(i)
+        batches = []
+        for index_list in batch_index_list:
+            phones_list, phones_len, all_phones, all_len, all_bert, texts = [], [], [], [], [], []
+            max_len = 0
+            for idx in index_list:
+                it = data[idx]
+                ph = torch.LongTensor(it["phones"]).to(device)
+                if prompt_data is not None:
+                    ap = torch.LongTensor(list(prompt_data["phones"]) + list(it["phones"])).to(device)
+                    ab = torch.cat([prompt_data["bert_features"], it["bert_features"]], 1).to(dtype=precision, device=device)
+                else:
+                    ap = ph
+                    ab = it["bert_features"].to(dtype=precision, device=device)
+                max_len = max(max_len, ab.shape[-1], ap.shape[-1])
+                phones_list.append(ph)
+                phones_len.append(ph.shape[-1])
+                all_phones.append(ap)
+                all_len.append(ap.shape[-1])
+                all_bert.append(ab)
+                texts.append(it["norm_text"])
+            batches.append({
+                "phones": phones_list, "phones_len": torch.LongTensor(phones_len).to(device),
+                "all_phones": all_phones, "all_phones_len": torch.LongTensor(all_len).to(device),
+                "all_bert_features": all_bert, "norm_text": texts, "max_len": max_len,
+            })
+        return batches, batch_index_list
+
+    def recovery_order(self, data: list, batch_index_list: list) -> list:
+        """put batch-ordered fragments back in submission order (TTS.py:957-973)."""
+        n = sum(len(b) for b in batch_index_list)
+        out = [None] * n
+        for i, index_list in enumerate(batch_index_list):
+            for j, index in enumerate(index_list):
+                out[index] = data[i][j]
+        return out
+
+    def audio_postprocess(self, audio: List[List[torch.Tensor]], sr: int, batch_index_list: Optional[list] = None,
+                          speed_factor: float = 1.0, split_bucket: bool = True, fragment_interval: float = 0.3,
+                          super_sampling: bool = False) -> Tuple[int, np.ndarray]:
+        """TTS.py:1377-1429: per fragment divide by its peak if the peak exceeds 1, append
+        int(sr*interval) zeros, restore order, concatenate, scale by 32768 and truncate to int16."""
+        if super_sampling:
+            raise NotImplementedError("audio super-sampling (v3 only) is out of scope")
+        dev = self.configs.device
+        zero = torch.zeros(int(self.configs.sampling_rate * fragment_interval), dtype=self.precision, device=dev)
+        for i, batch in enumerate(audio):
+            for j, frag in enumerate(batch):
+                peak = torch.abs(frag).max()
+                if peak > 1:
+                    frag = frag / peak
+                audio[i][j] = torch.cat([frag, zero], dim=0)
+        flat = self.recovery_order(audio, batch_index_list) if split_bucket else [f for b in audio for f in b]
+        self.last_fragment_lengths = [int(f.shape[0]) for f in flat]      # used by gsv.sharding
+        wav = torch.cat(flat, dim=0).cpu().numpy()
+        return sr, (wav * 32768).astype(np.int16)
+
+    # ---- the pipeline (reference TTS.py:984-1365) ---------------------------------------------
+    @torch.no_grad()
+    def run(self, inputs: dict) -> Generator[Tuple[int, np.ndarray], None, None]:
+        self.stop_flag = False
+        top_k = inputs.get("top_k", 5)
+        top_p = inputs.get("top_p", 1)
+        temperature = inputs.get("temperature", 1)
+        batch_size = inputs.get("batch_size", 1)
+        batch_threshold = inputs.get("batch_threshold", 0.75)
+        speed_factor = inputs.get("speed_factor", 1.0)
+        split_bucket = inputs.get("split_bucket", True)
+        return_fragment = inputs.get("return_fragment", False)
+        fragment_interval = inputs.get("fragment_interval", 0.3)
+        seed = inputs.get("seed", -1)
+        seed = -1 if seed in ["", None] else seed
+        actual_seed = set_seed(seed)
+        parallel_infer = inputs.get("parallel_infer", True)
+        repetition_penalty = inputs.get("repetition_penalty", 1.35)
+        if fragment_interval < 0.01:
+            fragment_interval = 0.01
+        if return_fragment and split_bucket:
+            split_bucket = False
+        if speed_factor != 1.0:
+            split_bucket = False
+        try:
+            if self.t2s_model is None or self.vits_model is None:
+                raise RuntimeError("init_t2s_weights / init_vits_weights first")
+            if self.prompt_cache["prompt_semantic"] is None or not self.prompt_cache["refer_spec"]:
+                raise NO_PROMPT_ERROR("set_prompt_cache() first (reference: ref_audio_path is required)")
+            t0 = time.perf_counter()
+            segments = inputs.get("segments")
+            if segments is None:
+                if self.text_frontend is None:
+                    raise NotImplementedError("raw text needs a text_frontend callable (G2P/BERT are outside the "
+                                              "hot-path scope); pass inputs['segments'] with phones/bert instead")
+                segments = self.text_frontend(inputs.get("text", ""), inputs.get("text_lang", ""),
+                                              inputs.get("text_split_method", "cut0"))
+            if len(segments) == 0:
+                yield 16000, np.zeros(16000, dtype=np.int16)
+                return
+            prompt_data = None
+            if self.prompt_cache["phones"] is not None:
+                prompt_data = {"phones": self.prompt_cache["phones"], "bert_features": self.prompt_cache["bert_features"]}
+            t1 = time.perf_counter()
+            data, batch_index_list = self.to_batch(segments, prompt_data=prompt_data, batch_size=batch_size,
+                                                   threshold=batch_threshold, split_bucket=split_bucket,
+                                                   device=self.configs.device, precision=self.precision)
+            t2 = time.perf_counter()
+            infer = (self.t2s_model.infer_panel_batch_infer if parallel_infer
+                     else self.t2s_model.infer_panel_naive_batched)
+            refer = [spec.to(device=self.configs.device) for spec, _ in self.prompt_cache["refer_spec"]]
+            up = math.prod(self.vits_model.upsample_rates)
+            audio, t_34, t_45 = [], 0.0, 0.0
+            sr = self.configs.sampling_rate
+            self.last_generated_tokens = 0
+            for bi, item in enumerate(data):
+                t3 = time.perf_counter()
+                n = len(item["all_phones"])
+                prompt = self.prompt_cache["prompt_semantic"].view(1, -1).expand(n, -1)
+                max_sec = self.configs.max_sec if self.configs.max_sec is not None else 54
+                pred_list, idx_list = infer(item["all_phones"], item["all_phones_len"], prompt,
+                                            item["all_bert_features"], top_k=top_k, top_p=top_p, temperature=temperature,
+                                            early_stop_num=self.configs.hz * max_sec, max_len=item["max_len"],
+                                            repetition_penalty=repetition_penalty, seed=actual_seed + bi)
+                torch.cuda.synchronize(self.configs.device)
+                t4 = time.perf_counter()
+                t_34 += t4 - t3
+                pred = [p[-i:] if i > 0 else p[:0] for p, i in zip(pred_list, idx_list)]
+                self.last_generated_tokens += int(sum(idx_list))
+                frags: List[torch.Tensor] = []
+                if speed_factor == 1.0:
+                    # one decode over the batch folded into the time axis (TTS.py:1259-1282)
+                    ends = np.cumsum([0] + [int(p.shape[0]) * 2 * up for p in pred])
+                    keep = [k for k, p in enumerate(pred) if p.shape[0] > 0]
+                    if keep:
+                        all_pred = torch.cat([pred[k] for k in keep]).view(1, 1, -1)
+                        all_ph = torch.cat([item["phones"][k] for k in keep]).view(1, -1)
+                        wav = self.vits_model.decode(all_pred, all_ph, refer, speed=speed_factor,
+                                                     seed=actual_seed + bi)[0, 0]
+                    else:
+                        wav = torch.zeros(0, dtype=self.precision, device=self.configs.device)
+                    o = 0
+                    for k, p in enumerate(pred):
+                        nsm = int(p.shape[0]) * 2 * up
+                        frags.append(wav[o:o + nsm])
+                        o += nsm
+                else:
+                    for k, p in enumerate(pred):
+                        frags.append(self.vits_model.decode(p.view(1, 1, -1), item["phones"][k].view(1, -1), refer,
+                                                            speed=speed_factor, seed=actual_seed + bi)[0, 0])
+                torch.cuda.synchronize(self.configs.device)
+                t5 = time.perf_counter()
+                t_45 += t5 - t4
+                if return_fragment:
+                    yield self.audio_postprocess([frags], sr, None, speed_factor, False, fragment_interval)
+                else:
+                    audio.append(frags)
+                if self.stop_flag:
+                    yield 16000, np.zeros(16000, dtype=np.int16)
+                    return
+            self.last_timing = (t1 - t0, t2 - t1, t_34, t_45)
+            if not return_fragment:
+                if len(audio) == 0:
+                    yield 16000, np.zeros(16000, dtype=np.int16)
+                    return
+                yield self.audio_postprocess(audio, sr, batch_index_list, speed_factor, split_bucket, fragment_interval)
+        except Exception as e:
+            traceback.print_exc()
+            # the reference yields 1 s of silence, rebuilds both models, then re-raises (TTS.py:1352-1363)
+            yield 16000, np.zeros(16000, dtype=np.int16)
+            try:
+                if self._t2s_state is not None and self._vits_state is not None:
+                    self.t2s_model = None
+                    self.vits_model = None
+                    self.init_t2s_weights(self.configs.t2s_weights_path, state=self._t2s_state)
+                    self.init_vits_weights(self.configs.vits_weights_path, state=self._vits_state)
+            finally:
+                raise e
+
+
+def load_sovits_new(path: str) -> dict:
+    """Reference process_ckpt.py:129-138: newer SoVITS files replace the zip magic `PK` with a 2-byte
+    version code; put `PK` back and load with a non-executing loader."""
+    import io
+    with open(path, "rb") as f:
+        head = f.read(2)
+        rest = f.read()
+    if head != b"PK":
+        data = io.BytesIO(b"PK" + rest)
+    else:
+        data = io.BytesIO(head + rest)
+    return torch.load(data, map_location="cpu", weights_only=True)

@@ -84,6 +84,9 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python gpt-sovits_amd/gsv/build.py` "
                                "(the gsv hot path has no CPU fallback)")
+        # torch first: it ships its own HIP runtime; loading ours before it puts two runtimes in one
+        # process and the second one finds no device
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             try:

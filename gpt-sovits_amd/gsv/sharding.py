@@ -1,0 +1,122 @@
+"""Utterance sharding across the GPUs of one node.
+
+The reference has no inference-side distribution.  After text segmentation every sentence is an
+independent job sharing one prompt, so the path shards by utterance: weights and the prompt cache
+are replicated, rank 0 scatters the tokenised segments, every rank runs AR -> decode locally with
+no steady-state communication, and rank 0 gathers the int16 fragments and restores submission
+order.  One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  Payloads are KB (ids) and ~256 KB per 4 s utterance (int16), so plain
+point-to-point collectives are used: one broadcast out, one length all-gather + one padded gather in.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def deal_contiguous(lengths: Sequence[int], world: int) -> List[List[int]]:
+    """Length-sort the items (stable) and give each rank one contiguous run of the sorted order, so a
+    rank's batches stay length-homogeneous (what to_batch's bucketing wants, reference
+    TTS_infer_pack/TTS.py:859-879).  Runs differ in size by at most one item."""
+    order = sorted(range(len(lengths)), key=lambda i: lengths[i])
+    n = len(order)
+    out, pos = [], 0
+    for r in range(world):
+        cnt = n // world + (1 if r < n % world else 0)
+        out.append(order[pos:pos + cnt])
+        pos += cnt
+    return out
+
+
+def pack_segments(segments: List[dict]) -> torch.Tensor:
+    """int32 wire format: [n, len_0 .. len_{n-1}, text_len_0 .. text_len_{n-1}, phones...].
+    BERT features are not shipped: the sharded path serves the non-zh case (all-zero features,
+    reference TextPreprocessor.py:216-220); zh callers shard after their own BERT pass."""
+    n = len(segments)
+    lens = [len(s["phones"]) for s in segments]
+    tl = [len(s["norm_text"]) for s in segments]
+    flat = [p for s in segments for p in s["phones"]]
+    return torch.tensor([n] + lens + tl + flat, dtype=torch.int32)
+
+
+def unpack_segments(buf: torch.Tensor) -> List[dict]:
+    a = buf.cpu().tolist()
+    n = a[0]
+    lens, tl = a[1:1 + n], a[1 + n:1 + 2 * n]
+    out, o = [], 1 + 2 * n
+    for i in range(n):
+        ph = a[o:o + lens[i]]
+        o += lens[i]
+        out.append({"phones": ph, "bert_features": torch.zeros(1024, lens[i]), "norm_text": "x" * tl[i]})
+    return out
+
+
+class ShardedSynthesizer:
+    """`synth(segments) -> (int16 1-D tensor on `device`, per-fragment sample counts in the order of
+    `segments`)` is the local engine call (TTS wrapper in production, a stub in the gloo tests)."""
+
+    def __init__(self, synth: Callable[[List[dict]], Tuple[torch.Tensor, List[int]]], device: torch.device,
+                 group=None):
+        self.synth = synth
+        self.device = device
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.world = dist.get_world_size(group) if self.on else 1
+
+    def run(self, segments: Optional[List[dict]]) -> Optional[np.ndarray]:
+        """rank 0 passes all segments (others pass None); rank 0 returns the int16 audio of all
+        fragments in submission order, the other ranks return None."""
+        dev = self.device
+        # ---- scatter (one broadcast of the packed batch; ranks slice their share)
+        if self.world > 1:
+            hdr = torch.zeros(1, dtype=torch.int64, device=dev)
+            if self.rank == 0:
+                wire = pack_segments(segments).to(dev)
+                hdr[0] = wire.numel()
+            dist.broadcast(hdr, 0, group=self.group)
+            if self.rank != 0:
+                wire = torch.empty(int(hdr.item()), dtype=torch.int32, device=dev)
+            dist.broadcast(wire, 0, group=self.group)
+            segments = unpack_segments(wire)
+        shares = deal_contiguous([len(s["norm_text"]) for s in segments], self.world)
+        mine = shares[self.rank]
+        audio, frag_lens = self.synth([segments[i] for i in mine]) if mine else (torch.zeros(0, dtype=torch.int16, device=dev), [])
+        assert audio.dtype == torch.int16 and sum(frag_lens) == audio.numel()
+        if self.world == 1:
+            return _reorder([audio.cpu().numpy()], [frag_lens], shares, len(segments))
+        # ---- gather (lengths, then one padded gather to rank 0)
+        n_local = torch.tensor([audio.numel()], dtype=torch.int64, device=dev)
+        all_n = [torch.zeros_like(n_local) for _ in range(self.world)]
+        dist.all_gather(all_n, n_local, group=self.group)
+        maxn = max(int(t.item()) for t in all_n)
+        pad = torch.zeros(max(maxn, 1), dtype=torch.int16, device=dev)
+        pad[: audio.numel()] = audio
+        maxf = max(len(s) for s in shares)
+        fl = torch.zeros(max(maxf, 1), dtype=torch.int64, device=dev)
+        if frag_lens:
+            fl[: len(frag_lens)] = torch.tensor(frag_lens, dtype=torch.int64, device=dev)
+        if self.rank == 0:
+            bufs = [torch.zeros_like(pad) for _ in range(self.world)]
+            fbufs = [torch.zeros_like(fl) for _ in range(self.world)]
+            dist.gather(pad, bufs, dst=0, group=self.group)
+            dist.gather(fl, fbufs, dst=0, group=self.group)
+            arrays = [b[: int(n.item())].cpu().numpy() for b, n in zip(bufs, all_n)]
+            lens = [f[: len(s)].cpu().tolist() for f, s in zip(fbufs, shares)]
+            return _reorder(arrays, lens, shares, len(segments))
+        dist.gather(pad, None, dst=0, group=self.group)
+        dist.gather(fl, None, dst=0, group=self.group)
+        return None
+
+
+def _reorder(arrays: List[np.ndarray], frag_lens: List[List[int]], shares: List[List[int]], n: int) -> np.ndarray:
+    frags: List[Optional[np.ndarray]] = [None] * n
+    for arr, lens, idxs in zip(arrays, frag_lens, shares):
+        o = 0
+        for ln, i in zip(lens, idxs):
+            frags[i] = arr[o:o + ln]
+            o += ln
+    return np.concatenate([f for f in frags if f is not None]) if n else np.zeros(0, dtype=np.int16)
