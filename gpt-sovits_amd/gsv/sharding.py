@@ -93,8 +93,10 @@ class ShardedSynthesizer:
         all_n = [torch.zeros_like(n_local) for _ in range(self.world)]
         dist.all_gather(all_n, n_local, group=self.group)
         maxn = max(int(t.item()) for t in all_n)
-        pad = torch.zeros(max(maxn, 1), dtype=torch.int16, device=dev)
-        pad[: audio.numel()] = audio
+        # int16 samples travel as raw bytes: neither RCCL nor gloo has a 16-bit integer type
+        pad16 = torch.zeros(max(maxn, 1), dtype=torch.int16, device=dev)
+        pad16[: audio.numel()] = audio
+        pad = pad16.view(torch.uint8)
         maxf = max(len(s) for s in shares)
         fl = torch.zeros(max(maxf, 1), dtype=torch.int64, device=dev)
         if frag_lens:
@@ -104,7 +106,7 @@ class ShardedSynthesizer:
             fbufs = [torch.zeros_like(fl) for _ in range(self.world)]
             dist.gather(pad, bufs, dst=0, group=self.group)
             dist.gather(fl, fbufs, dst=0, group=self.group)
-            arrays = [b[: int(n.item())].cpu().numpy() for b, n in zip(bufs, all_n)]
+            arrays = [b.view(torch.int16)[: int(n.item())].cpu().numpy() for b, n in zip(bufs, all_n)]
             lens = [f[: len(s)].cpu().tolist() for f, s in zip(fbufs, shares)]
             return _reorder(arrays, lens, shares, len(segments))
         dist.gather(pad, None, dst=0, group=self.group)
