@@ -221,6 +221,36 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
     }
   }
 
+  // epilogue operands (bias, residual, row state) are fetched now, not after the LDS combine, so the
+  // kernel has one exposed memory round trip instead of two
+  constexpr int ITEMS = (CB + NW - 1) / NW;
+  f4 pre_bias[ITEMS], pre_res[ITEMS];
+  int pre_act[ITEMS], pre_pos[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int item = tid + it * NW * 64;
+    const int ln = item & 63;
+    const int b = (item >> 6) * 16 + (ln & 15);
+    const int n = n0 + 4 * (ln >> 4);
+    const bool ok = item < CB * 64 && b < a.B && n < a.N;
+    pre_bias[it] = (f4){0.f, 0.f, 0.f, 0.f};
+    pre_res[it] = (f4){0.f, 0.f, 0.f, 0.f};
+    pre_act[it] = 0; pre_pos[it] = 0;
+    if (ok) {
+      if (a.bias) {
+        if (n + 3 < a.N) pre_bias[it] = *(const f4*)(a.bias + n);
+        else for (int i = 0; i < 4; ++i) if (n + i < a.N) pre_bias[it][i] = a.bias[n + i];
+      }
+      if (a.epi == EPI_RESID) {
+        if (n + 3 < a.N) pre_res[it] = *(const f4*)(a.xres + (long long)b * a.N + n);
+        else for (int i = 0; i < 4; ++i) if (n + i < a.N) pre_res[it][i] = a.xres[(long long)b * a.N + n + i];
+      } else if (a.epi == EPI_QKV) {
+        pre_act[it] = a.active[b];
+        pre_pos[it] = a.kv_len[b];
+      }
+    }
+  }
+
   if (LNPRO) {
     constexpr int TPR = 8;                       // threads per row
     constexpr int RPP = NW * 64 / TPR;           // rows per pass
@@ -300,7 +330,10 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) *(f4v*)(red + ((wave * CB + cb) * 64 + lane) * 4) = acc[cb];
   __syncthreads();
-  for (int item = tid; item < CB * 64; item += NW * 64) {
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int item = tid + it * NW * 64;
+    if (item >= CB * 64) break;
     const int cb = item >> 6, ln = item & 63;
     f4v v = (f4v){0.f, 0.f, 0.f, 0.f};
     for (int w = 0; w < NW; ++w) v += *(const f4v*)(red + ((w * CB + cb) * 64 + ln) * 4);
@@ -310,35 +343,33 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
     if (b >= a.B || n >= a.N) continue;
     float o[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = v[i] + ((a.bias && n + i < a.N) ? a.bias[n + i] : 0.f);
+    for (int i = 0; i < 4; ++i) o[i] = v[i] + pre_bias[it][i];
+    const bool full = n + 3 < a.N;
     if (a.epi == EPI_RESID) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (n + i < a.N) a.out_f[(long long)b * a.N + n + i] = o[i] + a.xres[(long long)b * a.N + n + i];
+      float* op = a.out_f + (long long)b * a.N + n;
+      if (full) *(f4*)op = (f4){o[0] + pre_res[it][0], o[1] + pre_res[it][1], o[2] + pre_res[it][2], o[3] + pre_res[it][3]};
+      else for (int i = 0; i < 4; ++i) if (n + i < a.N) op[i] = o[i] + pre_res[it][i];
     } else if (a.epi == EPI_RELU) {
       T* op = (T*)a.out_t + (long long)b * a.N + n;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (n + i < a.N) op[i] = (T)fmaxf(o[i], 0.f);
+      typedef T T4 __attribute__((ext_vector_type(4)));
+      if (full) *(T4*)op = (T4){(T)fmaxf(o[0], 0.f), (T)fmaxf(o[1], 0.f), (T)fmaxf(o[2], 0.f), (T)fmaxf(o[3], 0.f)};
+      else for (int i = 0; i < 4; ++i) if (n + i < a.N) op[i] = (T)fmaxf(o[i], 0.f);
     } else if (a.epi == EPI_LOGITS) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (n + i < a.N) a.out_f[(long long)b * a.N + n + i] = o[i];
+      float* op = a.out_f + (long long)b * a.N + n;
+      for (int i = 0; i < 4; ++i) if (n + i < a.N) op[i] = o[i];     // N = 1025: rows are not 16-byte aligned
     } else {  // EPI_QKV: n in [0,3d): q -> qbuf, k/v -> cache row kv_len[b]
+      typedef T T4 __attribute__((ext_vector_type(4)));
       const int d = a.d, hd = d / a.H;
       const int which = n / d, c = n - which * d;
+      const T4 ov = (T4){(T)o[0], (T)o[1], (T)o[2], (T)o[3]};
       if (which == 0) {
-        T* op = (T*)a.out_t + (long long)b * d + c;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) op[i] = (T)o[i];
-      } else if (a.active[b]) {
+        *(T4*)((T*)a.out_t + (long long)b * d + c) = ov;
+      } else if (pre_act[it]) {
         const int h = c / hd, e = c - h * hd;
-        const int pos = a.kv_len[b];
+        const int pos = pre_pos[it];
         if (pos < a.smax) {
           T* base = (T*)(which == 1 ? a.kc : a.vc);
-          T* op = base + (((long long)b * a.H + h) * a.smax + pos) * hd + e;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) op[i] = (T)o[i];
+          *(T4*)(base + (((long long)b * a.H + h) * a.smax + pos) * hd + e) = ov;
         }
       }
     }
@@ -361,35 +392,41 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   constexpr int KPI = 64 / LPK;    // keys per wave-instruction
   typedef typename Frag16<T>::type F;
   const int h = blockIdx.x, b = blockIdx.y;
-  if (!active[b]) return;
-  const int n = min(kv_len[b] + 1, smax);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int part = lane % LPK, slot = lane / LPK;
   const int d = H * HD;
+  const T* kb = kc + ((long long)b * H + h) * smax * HD;
+  const T* vb = vc + ((long long)b * H + h) * smax * HD;
+  // q and the first SPEC key groups are fetched before the row state is known: the arena is
+  // allocated to smax, so the addresses are valid and groups beyond kv_len are simply masked.
+  // This takes the kv_len -> K/V dependency off the critical path (prompt + text is always longer
+  // than SPEC*4*KPI keys in practice, so nothing extra is streamed).
+  constexpr int SPEC = 2;
+  const F qv = *(const F*)(q + (long long)b * d + h * HD + part * G);
+  F ksp[SPEC], vsp[SPEC];
+#pragma unroll
+  for (int i = 0; i < SPEC; ++i) {
+    const int j = (wave + 4 * i) * KPI + slot;
+    if (j < smax) {
+      ksp[i] = *(const F*)(kb + (long long)j * HD + part * G);
+      vsp[i] = *(const F*)(vb + (long long)j * HD + part * G);
+    } else {
+#pragma unroll
+      for (int e = 0; e < G; ++e) { ksp[i][e] = 0; vsp[i][e] = 0; }
+    }
+  }
+  if (!active[b]) return;
+  const int n = min(kv_len[b] + 1, smax);
   float qf[G];
   {
-    F qv = *(const F*)(q + (long long)b * d + h * HD + part * G);
     const float scale = rsqrtf((float)HD);
 #pragma unroll
     for (int i = 0; i < G; ++i) qf[i] = to_f(qv[i]) * scale;
   }
-  const T* kb = kc + ((long long)b * H + h) * smax * HD;
-  const T* vb = vc + ((long long)b * H + h) * smax * HD;
   float m = -INFINITY, l = 0.f, acc[G];
 #pragma unroll
   for (int i = 0; i < G; ++i) acc[i] = 0.f;
-#pragma unroll 4
-  for (int j0 = wave * KPI; j0 < n; j0 += 4 * KPI) {
-    const int j = j0 + slot;
-    const bool ok = j < n;
-    F kv, vv;
-    if (ok) {
-      kv = *(const F*)(kb + (long long)j * HD + part * G);
-      vv = *(const F*)(vb + (long long)j * HD + part * G);
-    } else {
-#pragma unroll
-      for (int i = 0; i < G; ++i) { kv[i] = 0; vv[i] = 0; }
-    }
+  auto consume = [&](const F& kv, const F& vv, bool ok) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < G; ++i) s += qf[i] * to_f(kv[i]);
@@ -404,6 +441,22 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
       for (int i = 0; i < G; ++i) acc[i] = acc[i] * corr + p * to_f(vv[i]);
       m = mn;
     }
+  };
+#pragma unroll
+  for (int i = 0; i < SPEC; ++i) consume(ksp[i], vsp[i], (wave + 4 * i) * KPI + slot < n);
+#pragma unroll 4
+  for (int j0 = (wave + 4 * SPEC) * KPI; j0 < n; j0 += 4 * KPI) {
+    const int j = j0 + slot;
+    const bool ok = j < n;
+    F kv, vv;
+    if (ok) {
+      kv = *(const F*)(kb + (long long)j * HD + part * G);
+      vv = *(const F*)(vb + (long long)j * HD + part * G);
+    } else {
+#pragma unroll
+      for (int i = 0; i < G; ++i) { kv[i] = 0; vv[i] = 0; }
+    }
+    consume(kv, vv, ok);
   }
   // combine: global max, rescale, sum over key slots (lanes with equal `part`) and waves
   __shared__ float s_m[4];

@@ -114,10 +114,13 @@ class Text2SemanticDecoder:
             phones = torch.cat([t.reshape(-1) for t in x]).to(dev, torch.int32).contiguous()
             lens_h = (C.c_int32 * B)(*lens)
             bert_dev = None
-            if bert is not None:
-                nz = any(bool(torch.count_nonzero(b_).item()) for b_ in bert)
-                if nz:
-                    bert_dev = torch.cat([b_.reshape(1024, -1).t() for b_ in bert], 0).to(dev, torch.float32).contiguous()
+            if bert is not None and any(b_ is not None for b_ in bert):
+                # None = all-zero features (non-zh text): bert_proj(0) is its bias, handled in the engine
+                cols = [(torch.zeros(lens[i], 1024, device=dev) if b_ is None
+                         else b_.reshape(1024, -1).t().to(dev, torch.float32)) for i, b_ in enumerate(bert)]
+                allb = torch.cat(cols, 0).contiguous()
+                if bool(torch.any(allb)):            # one host sync for the whole batch
+                    bert_dev = allb
             pr = prompts.to(dev, torch.int32).contiguous()
             out_tokens = torch.zeros(B, budget, dtype=torch.int32, device=dev)
             out_len = torch.full((B,), -1, dtype=torch.int32, device=dev)
@@ -184,7 +187,7 @@ class Text2SemanticDecoder:
                           bert_feature: torch.Tensor, top_k: int = -100, top_p: int = 100, early_stop_num: int = -1,
                           temperature: float = 1.0, repetition_penalty: float = 1.35, **kwargs):
         """reference t2s_model.py:814-918: batch 1, EOS masked while idx < 11; returns (y[:, :-1], idx)."""
-        y, i = self._run([x[0]], prompts, [bert_feature[0]], top_k, top_p, early_stop_num, temperature,
+        y, i = self._run([x[0]], prompts, [bert_feature[0] if bert_feature is not None else None], top_k, top_p, early_stop_num, temperature,
                          repetition_penalty, eos_mask_steps=11, noise=kwargs.get("noise"), seed=kwargs.get("seed", 0),
                          max_steps=kwargs.get("max_steps", 1500))
         return y[0].unsqueeze(0), i[0]
@@ -198,7 +201,8 @@ class Text2SemanticDecoder:
         for i in range(len(x)):
             y, idx = self.infer_panel_naive(x[i].unsqueeze(0), x_lens[i] if x_lens is not None else None,
                                             prompts[i].unsqueeze(0) if prompts is not None else None,
-                                            bert_feature[i].unsqueeze(0), top_k, top_p, early_stop_num, temperature,
+                                            [bert_feature[i]] if bert_feature[i] is None else bert_feature[i].unsqueeze(0),
+                                            top_k, top_p, early_stop_num, temperature,
                                             repetition_penalty, **kwargs)
             y_list.append(y[0])
             idx_list.append(idx)

@@ -172,6 +172,18 @@ class TTS:
                     batch_index_list.append([])
                 batch_index_list[-1].append(i)
         batches = []
+        zero_cache: Dict[int, bool] = {}
+
+        def is_zero(t: Optional[torch.Tensor]) -> bool:
+            # all-zero BERT features (every non-zh segment, TextPreprocessor.py:216-220) are passed to the
+            # engine as None: bert_proj(0) is its bias, so the [1024, X] tensor never has to reach HBM
+            if t is None:
+                return True
+            k = id(t)
+            if k not in zero_cache:
+                zero_cache[k] = not bool(torch.any(t))
+            return zero_cache[k]
+
         for index_list in batch_index_list:
             phones_list, phones_len, all_phones, all_len, all_bert, texts = [], [], [], [], [], []
             max_len = 0
@@ -180,11 +192,22 @@ class TTS:
                 ph = torch.LongTensor(it["phones"]).to(device)
                 if prompt_data is not None:
                     ap = torch.LongTensor(list(prompt_data["phones"]) + list(it["phones"])).to(device)
-                    ab = torch.cat([prompt_data["bert_features"], it["bert_features"]], 1).to(dtype=precision, device=device)
+                    nb = (prompt_data["bert_features"].shape[-1] if prompt_data["bert_features"] is not None
+                          else len(prompt_data["phones"])) + \
+                         (it["bert_features"].shape[-1] if it["bert_features"] is not None else len(it["phones"]))
+                    if is_zero(prompt_data["bert_features"]) and is_zero(it["bert_features"]):
+                        ab = None
+                    else:
+                        pb = prompt_data["bert_features"]
+                        pb = torch.zeros(1024, len(prompt_data["phones"])) if pb is None else pb
+                        ib = it["bert_features"]
+                        ib = torch.zeros(1024, len(it["phones"])) if ib is None else ib
+                        ab = torch.cat([pb, ib], 1).to(dtype=precision, device=device)
                 else:
                     ap = ph
-                    ab = it["bert_features"].to(dtype=precision, device=device)
-                max_len = max(max_len, ab.shape[-1], ap.shape[-1])
+                    nb = it["bert_features"].shape[-1] if it["bert_features"] is not None else len(it["phones"])
+                    ab = None if is_zero(it["bert_features"]) else it["bert_features"].to(dtype=precision, device=device)
+                max_len = max(max_len, nb, ap.shape[-1])
                 phones_list.append(ph)
                 phones_len.append(ph.shape[-1])
                 all_phones.append(ap)
@@ -216,16 +239,22 @@ class TTS:
             raise NotImplementedError("audio super-sampling (v3 only) is out of scope")
         dev = self.configs.device
         zero = torch.zeros(int(self.configs.sampling_rate * fragment_interval), dtype=self.precision, device=dev)
+        frags = [f for batch in audio for f in batch]
+        # per-fragment peak without a host round trip per fragment: x / max(peak, 1) == x when peak <= 1
+        peaks = torch.stack([f.abs().max() if f.numel() else zero.new_zeros(()) for f in frags])
+        denom = torch.where(peaks > 1, peaks, torch.ones_like(peaks))
+        k = 0
         for i, batch in enumerate(audio):
             for j, frag in enumerate(batch):
-                peak = torch.abs(frag).max()
-                if peak > 1:
-                    frag = frag / peak
-                audio[i][j] = torch.cat([frag, zero], dim=0)
+                audio[i][j] = torch.cat([frag / denom[k], zero], dim=0)
+                k += 1
         flat = self.recovery_order(audio, batch_index_list) if split_bucket else [f for b in audio for f in b]
         self.last_fragment_lengths = [int(f.shape[0]) for f in flat]      # used by gsv.sharding
-        wav = torch.cat(flat, dim=0).cpu().numpy()
-        return sr, (wav * 32768).astype(np.int16)
+        wav = torch.cat(flat, dim=0)
+        # (x * 32768).astype(int16): C-style truncation, +32768 wraps to -32768 exactly as numpy does on the
+        # reference's host path; done on the device so only int16 crosses PCIe
+        pcm = (wav * 32768).to(torch.int32).to(torch.int16)
+        return sr, pcm.cpu().numpy()
 
     # ---- the pipeline (reference TTS.py:984-1365) ---------------------------------------------
     @torch.no_grad()
