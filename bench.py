@@ -177,8 +177,8 @@ def main():
                 "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
                 "algorithmic_bytes_per_launch": int(attn_bytes), "avg_launch_us": round(attn_ms * 1e3, 2),
                 "note": "one launch = one layer's K+V arena for all rows at the end-of-run cache length; "
-                        "HIP event pair around each of 10x24 launches inside the real per-layer kernel sequence "
-                        "on the engine stream (in situ: behind its producer GEMM, cold KV)"}
+                        "HIP events on the engine stream around 10x24 back-to-back launches over the 24 layers' "
+                        "distinct arenas (24 x 18 MB > Infinity Cache: every launch streams from HBM), rows forced active"}
         res = {
             "metric": "synthesised audio sec/sec (1/RTF), v2 pipeline", "value": round(audio_s / elapsed, 2),
             "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
