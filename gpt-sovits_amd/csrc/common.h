@@ -93,6 +93,8 @@ struct ConvArgs {
   long long xz = 0, wz = 0, yz = 0, rz = 0;  // batch strides in elements
 };
 int launch_conv_gemm(int dtype, const ConvArgs& a, hipStream_t s);
+// LDS-staged variant for stride-1 convs (conv_lds.hip): 0 = launched, 1 = not eligible, <0 = error
+int launch_conv_lds(int dtype, const ConvArgs& a, hipStream_t s);
 
 // elementwise / small ops (ops.hip)
 int launch_layernorm(int dtype, const void* x, int x_f32, const void* res, int res_f32, const float* gamma,

@@ -11,6 +11,8 @@
 // into the channels-last output.  fp16 uses v_mfma_f32_32x32x16_f16 (fp32 accumulate);
 // fp32 uses the exact-f32 v_mfma_f32_32x32x2_f32 with a permuted k order so that both
 // operands are still fetched as 16-byte contiguous chunks.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gsv {
@@ -198,6 +200,11 @@ int launch_conv_gemm(int dtype, const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
   if (a.T_virt == 0) a.T_virt = a.T_out;
   if (a.ups_u > 0 && a.ups_cout == 0) { set_error("conv_gemm: ups_cout missing"); return GSV_ERR_ARG; }
+  static const bool no_lds = getenv("GSV_NO_CONV_LDS") != nullptr;   // A/B switch for profiling
+  if (!no_lds) {
+    const int rc = launch_conv_lds(dtype, a, s);
+    if (rc <= 0) return rc;
+  }
   if (dtype == GSV_F16) return launch_t<_Float16>(a, s);
   if (dtype == GSV_F32) return launch_t<float>(a, s);
   set_error("conv_gemm: bad dtype %d", dtype);

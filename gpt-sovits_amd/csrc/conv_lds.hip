@@ -1,0 +1,370 @@
+// LDS-staged channels-last conv1d (stride 1) on MFMA -- the SoVITS generator's workhorse.
+//
+// conv_gemm.hip fetches every MFMA operand straight from L1/L2, which re-reads each input element
+// once per tap and each weight once per wave; that is fine for small/odd shapes but leaves the
+// generator's 90 ResBlock convs (95 % of SoVITS FLOPs) address-path bound.  Here a
+// workgroup owns a (CT output channels x TT time steps) tile:
+//   * the input window [TT + (taps-1)*|dil|][CC input channels] is staged ONCE per channel chunk into
+//     LDS (leaky-relu applied while staging, zero rows outside the sequence), so every tap is an LDS
+//     row shift instead of another global read -> HBM traffic drops to the algorithmic 1 read of x;
+//   * the weight slab of one tap [CT][CC] is staged once per workgroup (not per wave) and
+//     double-buffered: tap i+1 is in flight from L2 while tap i feeds the MFMAs, one barrier per tap;
+//   * rows are padded by 16 B so ds_read_b128 of 16 consecutive rows hits 64 distinct banks;
+//   * wave tile 64x128 (TM=2, TN=4 MFMA 32x32 tiles): 6 LDS fragment reads per 8 MFMAs.
+// Epilogue (bias, residual, scale, accumulate, tanh/relu, polyphase scatter) is the one of conv_gemm.
+#include "common.h"
+
+namespace gsv {
+
+template <typename T> struct FragL;
+template <> struct FragL<_Float16> { typedef h8 type; };
+template <> struct FragL<float> { typedef f4 type; };
+
+__device__ __forceinline__ void mma32l(f16v& acc, const h8& a, const h8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32l(f16v& acc, const f4& a, const f4& b) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+}
+
+template <typename F> __device__ __forceinline__ F zfrag() {
+  F z;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(F) / sizeof(z[0])); ++i) z[i] = 0;
+  return z;
+}
+__device__ __forceinline__ h8 lrelu_l(h8 v, float s) { h8 t = v * (_Float16)s; return __builtin_elementwise_max(v, t); }
+__device__ __forceinline__ f4 lrelu_l(f4 v, float s) { f4 t = v * s; return __builtin_elementwise_max(v, t); }
+__device__ __forceinline__ h8 relu_l(h8 v) { return __builtin_elementwise_max(v, zfrag<h8>()); }
+__device__ __forceinline__ f4 relu_l(f4 v) { return __builtin_elementwise_max(v, zfrag<f4>()); }
+
+template <typename T, int TM, int TN, int WM, int WN, int CC, bool ALLW, bool RES, bool ACCU>
+__global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int rows_win, int lo) {
+  typedef typename FragL<T>::type F;
+  constexpr int G = DT<T>::G;        // elements per 16-byte chunk
+  constexpr int KC = 2 * G;          // k per MFMA group
+  constexpr int CT = WM * TM * 32;   // output channels per workgroup
+  constexpr int TT = WN * TN * 32;   // time steps per workgroup
+  constexpr int NT = WM * WN * 64;
+  constexpr int LDX = CC + G;        // padded LDS row (elements)
+  constexpr int VPR = CC / G;        // 16-byte vectors per staged row
+  constexpr int WLOADS = (CT * VPR + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* xs = (T*)smem;                                   // [rows_win][LDX]
+  T* ws = xs + (size_t)rows_win * LDX;                // [2][CT][LDX]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int t0 = blockIdx.x * TT, cout0 = blockIdx.y * CT;
+  const T* __restrict__ x = (const T*)a.x;
+  const T* __restrict__ w = (const T*)a.w;
+  const int win_start = t0 - a.pad + lo;              // input row held in window row 0
+
+  f16v acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  // ---- epilogue operands are requested FIRST: every global round trip that is serialised inside a
+  // tile costs ~2 us with one or two workgroups per CU, so the residual / accumulate tiles and the bias
+  // ride in registers through the MFMA loop instead of being fetched (twice per pass) at the end.
+  constexpr int LDO = CT + 4;
+  constexpr int PR = TN * 32;                         // rows per epilogue pass (one wave column)
+  constexpr int IPR = CT / 4;                         // 4-channel items per tile row
+  constexpr int NI = PR * IPR / NT;                   // items per thread per pass
+  static_assert(PR * IPR % NT == 0 && NT % IPR == 0, "tile/thread mapping");
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  const bool vec_ok = ((a.ldy & 3) == 0) && ((a.y_col0 & 3) == 0) && ((a.ldr & 3) == 0) &&
+                      (a.ups_u == 0 || (a.ups_cout & 3) == 0);
+  const int ecg = tid % IPR;                          // this thread's channel group (same for all its items)
+  const int ec = cout0 + 4 * ecg;
+  int eoc = ec, epp = 0;
+  if (a.ups_u > 0) { epp = ec / a.ups_cout; eoc = ec - epp * a.ups_cout; }
+  const int env = max(0, min(4, a.Cout - ec));
+  f4 ebias = (f4){0.f, 0.f, 0.f, 0.f};
+  if (a.bias) for (int j = 0; j < env; ++j) ebias[j] = a.bias[eoc + j];
+  // the wide tile (CT = 128) keeps only the residual in registers; its accumulate operand is fetched per
+  // pass (that tile has ~19 us of MFMA work, the narrow ones have <2 us and must not stall at all)
+  constexpr bool PRE_ACC = ACCU && CT < 128;
+  constexpr int NRV = RES ? WN * NI : 1, NYV = PRE_ACC ? WN * NI : 1;
+  T4 rv[NRV], yv[NYV];
+  rv[0] = (T4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+  yv[0] = rv[0];
+#pragma unroll
+  for (int q = 0; q < ((RES || PRE_ACC) ? WN * NI : 0); ++q) {
+    if (RES) rv[q] = (T4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+    if (PRE_ACC) yv[q] = (T4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+    const int pass = q / NI, e = q - pass * NI;
+    const int tl = (tid + e * NT) / IPR;
+    const int t = t0 + pass * PR + tl;
+    const int orow = a.ups_u > 0 ? t * a.ups_u + epp - a.ups_pad : t;
+    const bool ok = t < a.T_virt && env > 0 && orow >= 0 && orow < a.T_out;
+    if (!ok) continue;
+    if (RES) {
+      const T* rp = (const T*)a.res + (long long)orow * a.ldr + eoc;
+      if (vec_ok && env == 4) rv[q] = *(const T4*)rp;
+      else for (int j = 0; j < env; ++j) rv[q][j] = rp[j];
+    }
+    if (PRE_ACC) {
+      const T* yp = (const T*)a.y + (long long)orow * a.ldy + a.y_col0 + eoc;
+      if (vec_ok && env == 4) yv[q] = *(const T4*)yp;
+      else for (int j = 0; j < env; ++j) yv[q][j] = yp[j];
+    }
+  }
+
+  // weight staging assignment: vector index v -> (row = v / VPR, col = v % VPR)
+  auto load_w = [&](int tap, int cc0, F* regs) {
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i) {
+      const int v = tid + i * NT;
+      const int row = v / VPR, col = v - row * VPR;
+      const int co = cout0 + row;
+      const int ci = cc0 + col * G;
+      regs[i] = (row < CT && co < a.Cout && ci < a.Cin)
+                    ? *(const F*)(w + (long long)co * a.ldw + (long long)tap * a.Cin + ci)
+                    : zfrag<F>();
+    }
+  };
+  auto store_w = [&](int buf, const F* regs) {
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i) {
+      const int v = tid + i * NT;
+      const int row = v / VPR, col = v - row * VPR;
+      if (row < CT) *(F*)(ws + ((size_t)buf * CT + row) * LDX + col * G) = regs[i];
+    }
+  };
+
+  for (int cc0 = 0; cc0 < a.Cin; cc0 += CC) {
+    __syncthreads();   // every wave is done with the previous chunk's window and weight buffers
+    // ---- stage the input window of this channel chunk (pre-activation applied once here).
+    // Loads are issued XB at a time before any LDS store so a thread has XB independent 16-byte
+    // requests in flight (a load->store loop would serialise one HBM round trip per vector).
+    {
+      F w0[WLOADS];
+      if (!ALLW) load_w(0, cc0, w0);
+      constexpr int XB = (306 * VPR + NT - 1) / NT;   // the whole window (<= 306 rows) in one batch of independent loads
+      const int total = rows_win * VPR;
+      for (int v0 = 0; v0 < total; v0 += XB * NT) {
+        F tmp[XB];
+#pragma unroll
+        for (int i = 0; i < XB; ++i) {
+          const int v = v0 + tid + i * NT;
+          const int row = v / VPR, col = v - row * VPR;
+          const int ti = win_start + row;
+          const int ci = cc0 + col * G;
+          tmp[i] = (v < total && ti >= 0 && ti < a.T_in && ci < a.Cin) ? *(const F*)(x + (long long)ti * a.ldx + ci) : zfrag<F>();
+        }
+#pragma unroll
+        for (int i = 0; i < XB; ++i) {
+          const int v = v0 + tid + i * NT;
+          if (v < total) {
+            const int row = v / VPR, col = v - row * VPR;
+            F val = tmp[i];
+            if (a.pre_act == ACT_LRELU) val = lrelu_l(val, a.pre_slope);
+            else if (a.pre_act == ACT_RELU) val = relu_l(val);
+            *(F*)(xs + (size_t)row * LDX + col * G) = val;
+          }
+        }
+      }
+      if (!ALLW) store_w(0, w0);
+      else {
+        // narrow layers: every tap's weight slab fits in LDS, so the tap loop needs no barrier at all
+        const int totw = a.taps * CT * VPR;
+        for (int v0 = 0; v0 < totw; v0 += 4 * NT) {
+          F tmp[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int v = v0 + tid + i * NT;
+            const int tap = v / (CT * VPR), rem = v - tap * (CT * VPR);
+            const int row = rem / VPR, col = rem - row * VPR;
+            const int co = cout0 + row, ci = cc0 + col * G;
+            tmp[i] = (v < totw && co < a.Cout && ci < a.Cin)
+                         ? *(const F*)(w + (long long)co * a.ldw + (long long)tap * a.Cin + ci) : zfrag<F>();
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int v = v0 + tid + i * NT;
+            if (v < totw) {
+              const int tap = v / (CT * VPR), rem = v - tap * (CT * VPR);
+              const int row = rem / VPR, col = rem - row * VPR;
+              *(F*)(ws + ((size_t)tap * CT + row) * LDX + col * G) = tmp[i];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int ksteps = min(CC, a.Cin - cc0) / KC;
+    for (int tap = 0; tap < a.taps; ++tap) {
+      const int buf = ALLW ? tap : (tap & 1);
+      F nxt[WLOADS];
+      const bool more = !ALLW && tap + 1 < a.taps;
+      if (more) load_w(tap + 1, cc0, nxt);
+      const int shift = tap * a.dil - lo;             // window row of output column 0 for this tap
+      const T* wb = ws + (size_t)buf * CT * LDX;
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const int kk = ks * KC + G * h;
+        F af[TM], bf[TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) af[m] = *(const F*)(wb + (size_t)((wm * TM + m) * 32 + r) * LDX + kk);
+#pragma unroll
+        for (int n = 0; n < TN; ++n) bf[n] = *(const F*)(xs + (size_t)((wn * TN + n) * 32 + r + shift) * LDX + kk);
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) mma32l(acc[m][n], af[m], bf[n]);
+      }
+      if (more) {
+        store_w(buf ^ 1, nxt);
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue.  The MFMA accumulator layout gives a lane 4 channels of ONE time step, i.e. a wave
+  // store would touch 32 different rows with 8-16 B each.  Instead the fp32 tile goes through LDS (one
+  // wave column per pass) and is written as whole channels-last rows: consecutive lanes -> consecutive
+  // 8-16 B, so HBM sees full lines.  No global load happens here (operands were preloaded above).
+  float* os = (float*)smem;                           // [PR][LDO], reuses the staging buffers
+#pragma unroll
+  for (int pass = 0; pass < WN; ++pass) {
+    __syncthreads();
+    if (wn == pass) {
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+          const int tl = n * 32 + r;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cl = (wm * TM + m) * 32 + 8 * g + 4 * h;
+            *(f4*)(os + (size_t)tl * LDO + cl) = (f4){acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+          }
+        }
+    }
+    __syncthreads();
+    T4 ya[NI];
+    if (ACCU && !PRE_ACC) {
+#pragma unroll
+      for (int e = 0; e < NI; ++e) {
+        ya[e] = (T4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+        const int tl = (tid + e * NT) / IPR;
+        const int t = t0 + pass * PR + tl;
+        const int orow = a.ups_u > 0 ? t * a.ups_u + epp - a.ups_pad : t;
+        if (!(t < a.T_virt && env > 0 && orow >= 0 && orow < a.T_out)) continue;
+        const T* yp = (const T*)a.y + (long long)orow * a.ldy + a.y_col0 + eoc;
+        if (vec_ok && env == 4) ya[e] = *(const T4*)yp;
+        else for (int j = 0; j < env; ++j) ya[e][j] = yp[j];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+      const int q = pass * NI + e;
+      const int tl = (tid + e * NT) / IPR;
+      const int t = t0 + pass * PR + tl;
+      const int orow = a.ups_u > 0 ? t * a.ups_u + epp - a.ups_pad : t;
+      if (!(t < a.T_virt && env > 0 && orow >= 0 && orow < a.T_out)) continue;
+      const f4 av = *(const f4*)(os + (size_t)tl * LDO + 4 * ecg);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float u = av[j] + ebias[j];
+        if (RES) u += to_f(rv[q][j]);
+        u *= a.scale;
+        if (a.post_act == ACT_RELU) u = fmaxf(u, 0.f);
+        else if (a.post_act == ACT_TANH) u = tanhf(u);
+        else if (a.post_act == ACT_MISH) u = u * tanhf(u > 20.f ? u : log1pf(expf(u)));
+        if (PRE_ACC) u += to_f(yv[q][j]);
+        else if (ACCU) u += to_f(ya[e][j]);
+        v[j] = u;
+      }
+      const long long yoff = (long long)orow * a.ldy + a.y_col0 + eoc;
+      const bool vec = vec_ok && env == 4;
+      if (a.out_f32) {
+        float* yp = (float*)a.y + yoff;
+        if (vec) *(f4*)yp = (f4){v[0], v[1], v[2], v[3]};
+        else for (int j = 0; j < env; ++j) yp[j] = v[j];
+      } else {
+        T* yp = (T*)a.y + yoff;
+        if (vec) *(T4*)yp = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+        else for (int j = 0; j < env; ++j) yp[j] = (T)v[j];
+      }
+    }
+  }
+}
+
+template <typename T, int TM, int TN, int WM, int WN, int CC, bool ALLW, bool RES, bool ACCU>
+static int launch_inst2(const ConvArgs& a, int rows_win, int lo, hipStream_t s) {
+  constexpr int G = DT<T>::G;
+  constexpr int CT = WM * TM * 32, TT = WN * TN * 32;
+  size_t lds = ((size_t)rows_win + (ALLW ? a.taps : 2) * CT) * (CC + G) * sizeof(T);
+  const size_t lds_epi = (size_t)TN * 32 * (CT + 4) * sizeof(float);
+  if (lds_epi > lds) lds = lds_epi;
+  auto kern = conv_lds_kernel<T, TM, TN, WM, WN, CC, ALLW, RES, ACCU>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (lds > 160 * 1024) { set_error("conv_lds: window needs %zu B of LDS", lds); return GSV_ERR_ARG; }
+  dim3 grid(cdiv(a.T_virt, TT), cdiv(a.Cout, CT), 1);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, a, rows_win, lo);
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+template <typename T, int TM, int TN, int WM, int WN, int CC, bool ALLW>
+static int launch_inst(const ConvArgs& a, int rows_win, int lo, hipStream_t s) {
+  const bool res = a.res != nullptr, acc = a.accumulate != 0;
+  if (res && acc) return launch_inst2<T, TM, TN, WM, WN, CC, ALLW, true, true>(a, rows_win, lo, s);
+  if (res) return launch_inst2<T, TM, TN, WM, WN, CC, ALLW, true, false>(a, rows_win, lo, s);
+  if (acc) return launch_inst2<T, TM, TN, WM, WN, CC, ALLW, false, true>(a, rows_win, lo, s);
+  return launch_inst2<T, TM, TN, WM, WN, CC, ALLW, false, false>(a, rows_win, lo, s);
+}
+
+template <typename T, int CT, int CC> static bool fits(int rows, int wslabs = 2) {
+  return ((size_t)rows + (size_t)wslabs * CT) * (CC + DT<T>::G) * sizeof(T) <= 160 * 1024;
+}
+
+// returns 1 if the problem is not eligible (caller falls back to conv_gemm), 0 on success, <0 on error
+template <typename T> static int try_launch(const ConvArgs& a, hipStream_t s) {
+  constexpr int G = DT<T>::G;
+  constexpr int KC = 2 * G;
+  constexpr int CCBIG = 256 / (int)sizeof(T);   // 128 fp16 / 64 fp32 input channels per chunk
+  if (a.Z != 1 || a.stride != 1 || a.Cin % KC != 0 || a.T_virt < 256) return 1;
+  if ((a.res && a.res_f32) || (a.accumulate && a.out_f32)) return 1;   // preloaded operands are engine-dtype tiles
+  if (a.ldx % G != 0 || a.ldw % G != 0 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return 1;
+  const int span = (a.taps - 1) * (a.dil < 0 ? -a.dil : a.dil);
+  if (span > 50) return 1;                      // staging batch is sized for windows of <= 306 rows
+  const int lo = a.dil < 0 ? (a.taps - 1) * a.dil : 0;
+  const int rows = 256 + span;                  // every configuration owns 256 time steps
+  if (a.Cout > 64) {
+    if (a.Cin >= CCBIG && fits<T, 128, CCBIG>(rows)) return launch_inst<T, 2, 4, 2, 2, CCBIG, false>(a, rows, lo, s);
+    if (a.Cin >= CCBIG / 2 && fits<T, 128, CCBIG / 2>(rows)) return launch_inst<T, 2, 4, 2, 2, CCBIG / 2, false>(a, rows, lo, s);
+    return 1;
+  }
+  if (a.Cout > 32) {
+    if (a.Cin % 64 == 0 && fits<T, 64, 64>(rows)) return launch_inst<T, 2, 2, 1, 4, 64, false>(a, rows, lo, s);
+    if (a.Cin % 32 == 0 && fits<T, 64, 32>(rows)) return launch_inst<T, 2, 2, 1, 4, 32, false>(a, rows, lo, s);
+    return 1;
+  }
+  // narrow layers (HBM-bound): all taps' weights resident in LDS, no barrier in the tap loop; small
+  // register / LDS footprint so that several workgroups per CU overlap their single load round trip
+  if (a.Cin % 64 == 0 && fits<T, 32, 64>(rows, a.taps)) return launch_inst<T, 1, 2, 1, 4, 64, true>(a, rows, lo, s);
+  if (a.Cin % 32 == 0 && fits<T, 32, 32>(rows, a.taps)) return launch_inst<T, 1, 2, 1, 4, 32, true>(a, rows, lo, s);
+  if (a.Cin % 16 == 0 && fits<T, 32, 16>(rows, a.taps)) return launch_inst<T, 1, 2, 1, 4, 16, true>(a, rows, lo, s);
+  return 1;
+}
+
+int launch_conv_lds(int dtype, const ConvArgs& a, hipStream_t s) {
+  if (dtype == GSV_F16) return try_launch<_Float16>(a, s);
+  if (dtype == GSV_F32) return try_launch<float>(a, s);
+  return 1;
+}
+
+}  // namespace gsv

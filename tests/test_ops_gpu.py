@@ -120,3 +120,57 @@ def test_layernorm_matches_torch():
                                                y.data_ptr(), 37, 512, 1e-5, _lib.dtype_code(dtype), None))
         torch.cuda.synchronize()
         assert (y.float().cpu() - ref).abs().max() < tol * 10
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.float16, 2e-2)])
+@pytest.mark.parametrize("Cin,Cout,k,dil,T", [(256, 256, 11, 5, 700), (192, 512, 7, 1, 300), (128, 128, 3, 3, 1111),
+                                               (64, 64, 7, 5, 2000), (32, 32, 11, 1, 1500), (16, 16, 3, 5, 4100),
+                                               (16, 1, 7, 1, 3000), (768, 192, 3, 1, 260), (192, 384, 5, 1, 513),
+                                               (96, 192, 1, 1, 400)])
+def test_conv1d_lds_path_matches_torch(dtype, tol, Cin, Cout, k, dil, T):
+    """T >= 256 and stride 1 route through the LDS-staged kernel (conv_lds.hip): every tile config,
+    partial channel chunks (192 = 128 + 64), halo rows outside the sequence, Cout = 1 (conv_post)."""
+    torch.manual_seed(Cin + Cout + k)
+    x = torch.randn(Cin, T)
+    w = torch.randn(Cout, Cin, k) / (Cin * k) ** 0.5
+    b = torch.randn(Cout)
+    res = torch.randn(Cout, T)
+    ref = F.conv1d(F.leaky_relu(x, 0.1).unsqueeze(0), w, b, padding=(k * dil - dil) // 2, dilation=dil)[0] + res
+    got = _conv(x, w, b, dtype, dil=dil, pre_lrelu=0.1, res=res)
+    assert (got - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    # scale + accumulate (the MRF mean of the generator, models.py:459-466)
+    prev = torch.randn(Cout, T)
+    ref2 = prev + (F.conv1d(x.unsqueeze(0), w, b, padding=(k * dil - dil) // 2, dilation=dil)[0] + res) / 3.0
+    got2 = _conv(x, w, b, dtype, dil=dil, res=res, scale=1.0 / 3.0, accumulate=prev)
+    assert (got2 - ref2).abs().max().item() < tol * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("u,k,Cin,Cout,T", [(10, 16, 512, 256, 300), (8, 16, 256, 128, 600), (2, 8, 128, 64, 1000),
+                                             (2, 2, 64, 32, 2500), (2, 2, 32, 16, 3000)])
+def test_transposed_conv_lds_path(u, k, Cin, Cout, T):
+    from gsv import _lib
+    _lib.init(0)
+    torch.manual_seed(u + k + Cin)
+    dtype = torch.float16
+    x = torch.randn(Cin, T)
+    w = torch.randn(Cin, Cout, k) / (Cin * k / u) ** 0.5
+    b = torch.randn(Cout)
+    pad = (k - u) // 2
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1).unsqueeze(0), w, b, stride=u, padding=pad)[0]
+    taps = -(-k // u)
+    wv = torch.zeros(u * Cout, taps, Cin)
+    for p in range(u):
+        for q in range(taps):
+            j = q * u + p
+            if j < k:
+                wv[p * Cout:(p + 1) * Cout, q, :] = w[:, :, j].t()
+    xd = x.t().contiguous().to(DEV, dtype)
+    wd = wv.reshape(u * Cout, taps * Cin).contiguous().to(DEV, dtype)
+    bd = b.to(DEV)
+    T_out = T * u
+    y = torch.zeros(T_out, Cout, device=DEV, dtype=dtype)
+    d = _lib.ConvDesc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), None, T, T_out, Cin, u * Cout, taps, 1,
+                      -1, 0, 3, 0.1, 0, 1.0, 0, 0, u, pad)
+    _lib.check(_lib.lib().gsv_op_conv1d(C.byref(d), _lib.dtype_code(dtype), None))
+    torch.cuda.synchronize()
+    assert (y.float().cpu().t() - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
