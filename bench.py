@@ -173,8 +173,14 @@ def main():
         # --- roofline of the dominant AR kernel: decode attention streaming the KV arena
         attn_ms, attn_bytes, step_bytes, layers_ms = tts.t2s_model.time_attention(iters=10)
         ach = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
+        # HBM traffic per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE collected
+        # in separate rocprofv3 runs of this command, gfx950 2x read correction applied); valid for this workload
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
+        if os.path.exists(tj) and B == 32 and TOK == 100 and not args.fp32:
+            traffic = json.load(open(tj)).get("traffic_bytes_per_launch")
         roof = {"kernel": "decode_attn_kernel<f16,32>", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(attn_bytes), "avg_launch_us": round(attn_ms * 1e3, 2),
                 "note": "one launch = one layer's K+V arena for all rows at the end-of-run cache length; "
                         "HIP events on the engine stream around 10x24 back-to-back launches over the 24 layers' "
