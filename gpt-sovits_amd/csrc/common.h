@@ -67,7 +67,7 @@ static inline size_t dt_size(int dt) { return dt == GSV_F16 ? 2 : 4; }
 // ------------------------------------------------------------------------------------
 // generic channels-last implicit-GEMM conv (conv_gemm.hip)
 // ------------------------------------------------------------------------------------
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3, ACT_MISH = 4 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3, ACT_MISH = 4, ACT_CLAMP1 = 5 };
 
 struct ConvArgs {
   const void* x = nullptr;   // [Z][T_in][ldx] activations, channels-last

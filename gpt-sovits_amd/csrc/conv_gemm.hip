@@ -153,7 +153,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(ConvArgs a) {
           u *= a.scale;
           if (a.post_act == ACT_RELU) u = fmaxf(u, 0.f);
           else if (a.post_act == ACT_TANH) u = tanhf(u);
-          else if (a.post_act == ACT_MISH) u = u * tanhf(u > 20.f ? u : log1pf(expf(u)));  // x*tanh(softplus(x))
+          else if (a.post_act == ACT_MISH) u = u * tanhf(u > 20.f ? u : log1pf(expf(u)));
+        else if (a.post_act == ACT_CLAMP1) u = fminf(fmaxf(u, -1.f), 1.f);  // x*tanh(softplus(x))
           if (a.accumulate) u += a.out_f32 ? ((float*)a.y)[yoff + j] : to_f(((T*)a.y)[yoff + j]);
           v[j] = u;
         }

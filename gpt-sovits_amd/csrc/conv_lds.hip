@@ -279,6 +279,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
         if (a.post_act == ACT_RELU) u = fmaxf(u, 0.f);
         else if (a.post_act == ACT_TANH) u = tanhf(u);
         else if (a.post_act == ACT_MISH) u = u * tanhf(u > 20.f ? u : log1pf(expf(u)));
+        else if (a.post_act == ACT_CLAMP1) u = fminf(fmaxf(u, -1.f), 1.f);
         if (PRE_ACC) u += to_f(yv[q][j]);
         else if (ACCU) u += to_f(ya[e][j]);
         v[j] = u;

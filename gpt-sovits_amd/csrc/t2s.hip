@@ -442,10 +442,27 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
       m = mn;
     }
   };
+  // second batch: as soon as kv_len is known, the next NEXT groups are requested BEFORE the speculative
+  // ones are consumed, so both batches share one memory round trip (up to (SPEC+NEXT)*4*KPI = 512 fp16 keys)
+  constexpr int NEXT = 5;
+  F kn[NEXT], vn[NEXT];
+#pragma unroll
+  for (int i = 0; i < NEXT; ++i) {
+    const int j = (wave + 4 * (SPEC + i)) * KPI + slot;
+    if (j < n) {
+      kn[i] = *(const F*)(kb + (long long)j * HD + part * G);
+      vn[i] = *(const F*)(vb + (long long)j * HD + part * G);
+    } else {
+#pragma unroll
+      for (int e = 0; e < G; ++e) { kn[i][e] = 0; vn[i][e] = 0; }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < SPEC; ++i) consume(ksp[i], vsp[i], (wave + 4 * i) * KPI + slot < n);
+#pragma unroll
+  for (int i = 0; i < NEXT; ++i) consume(kn[i], vn[i], (wave + 4 * (SPEC + i)) * KPI + slot < n);
 #pragma unroll 4
-  for (int j0 = (wave + 4 * SPEC) * KPI; j0 < n; j0 += 4 * KPI) {
+  for (int j0 = (wave + 4 * (SPEC + NEXT)) * KPI; j0 < n; j0 += 4 * KPI) {
     const int j = j0 + slot;
     const bool ok = j < n;
     F kv, vv;

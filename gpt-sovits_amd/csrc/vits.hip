@@ -34,7 +34,8 @@ __global__ void gather_rows_kernel(const int* __restrict__ idx, const float* __r
 
 // fp32 channels-first [C_total][T] -> T channels-last [T][C] (first C channels)
 template <typename T>
-__global__ void cf_to_cl_kernel(const float* __restrict__ src, int Tn, int C, T* __restrict__ dst) {
+__global__ void cf_to_cl_kernel(const float* __restrict__ src, int Tn, int C, T* __restrict__ dst, int ldd = 0) {
+  if (ldd == 0) ldd = C;
   __shared__ float tile[32][33];
   const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -45,7 +46,64 @@ __global__ void cf_to_cl_kernel(const float* __restrict__ src, int Tn, int C, T*
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     int t = t0 + i, c = c0 + tx;
-    if (t < Tn && c < C) dst[(long long)t * C + c] = (T)tile[tx][i];
+    if (t < Tn && c < C) dst[(long long)t * ldd + c] = (T)tile[tx][i];
+  }
+}
+
+// Anti-aliased snake / snakebeta on channels-last activations [T][C] (BigVGAN Activation1d,
+// alias_free_activation/torch/act.py:25-30): 2x zero-stuffed 12-tap up-FIR -> x + sin^2(a x)/(b+1e-9)
+// -> 12-tap stride-2 down-FIR, replicate padding as in aa.hip.  A workgroup owns 64 time steps x 64
+// channels: rows are read/written 128 B wide (lane = channel), the 2x-rate intermediate lives in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void aa_act_cl_kernel(const T* __restrict__ x, T* __restrict__ y, int Tn, int C, int ld,
+                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                        int logscale, const float* __restrict__ up12,
+                                                        const float* __restrict__ dn12) {
+  constexpr int TT = 64, CW = 64;
+  __shared__ float xs[TT + 16][CW];
+  __shared__ float as[2 * TT + 16][CW];
+  __shared__ float uf[12], df[12];
+  const int t0 = blockIdx.x * TT, c0 = blockIdx.y * CW;
+  const int cl = threadIdx.x & 63, tq = threadIdx.x >> 6;
+  const int c = c0 + cl;
+  const bool cok = c < C;
+  if (threadIdx.x < 12) { uf[threadIdx.x] = up12[threadIdx.x]; df[threadIdx.x] = dn12[threadIdx.x]; }
+  float a = 1.f, ib = 1.f;
+  if (cok) {
+    a = logscale ? expf(alpha[c]) : alpha[c];
+    ib = 1.f / ((logscale ? expf(beta[c]) : beta[c]) + 1e-9f);
+  }
+  for (int i = tq; i < TT + 16; i += 4) {
+    const int t = min(max(t0 - 8 + i, 0), Tn - 1);
+    xs[i][cl] = cok ? to_f(x[(long long)t * ld + c]) : 0.f;
+  }
+  __syncthreads();
+  const int n0 = 2 * t0 - 8;
+  for (int k = tq; k < 2 * TT + 16; k += 4) {
+    const int n = min(max(n0 + k, 0), 2 * Tn - 1);
+    const int ilo = (n + 5) >> 1;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int i = ilo + j;
+      const int f = n + 15 - 2 * i;
+      if (f >= 0 && f < 12) {
+        const int xo = min(max(i - 5, 0), Tn - 1);
+        acc += xs[xo - (t0 - 8)][cl] * uf[f];
+      }
+    }
+    const float u = 2.f * acc;
+    const float sn = sinf(u * a);
+    as[k][cl] = u + ib * sn * sn;
+  }
+  __syncthreads();
+  for (int i = tq; i < TT; i += 4) {
+    const int t = t0 + i;
+    if (t >= Tn || !cok) continue;
+    float acc = 0.f;
+#pragma unroll
+    for (int f = 0; f < 12; ++f) acc += df[f] * as[2 * i + f + 3][cl];
+    y[(long long)t * ld + c] = (T)acc;
   }
 }
 
@@ -217,6 +275,20 @@ __global__ void mean_time_kernel(const T* __restrict__ x, int Tn, int C, float w
   float s = 0.f;
   for (int t = 0; t < Tn; ++t) s += to_f(x[(long long)t * C + c]) / (float)Tn;
   out[c] = (accumulate ? out[c] : 0.f) + s * wgt;
+}
+
+// F.interpolate(mode="linear", align_corners=False) along time on channels-last rows (models.py:226-228)
+template <typename T>
+__global__ void interp_linear_kernel(const T* __restrict__ x, int Tin, int Tout, int C, T* __restrict__ y) {
+  const int t = blockIdx.x;
+  const float scale = (float)Tin / (float)Tout;
+  float src = scale * ((float)t + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  const int i0 = min((int)src, Tin - 1);
+  const int i1 = min(i0 + 1, Tin - 1);
+  const float w1 = src - (float)i0, w0 = 1.f - w1;
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    y[(long long)t * C + c] = (T)(w0 * to_f(x[(long long)i0 * C + c]) + w1 * to_f(x[(long long)i1 * C + c]));
 }
 
 __global__ void vec_add_kernel(const float* a, const float* b, float* out, int n) {
@@ -739,7 +811,7 @@ int gsv_vits_set_refer(gsv_vits_t* h, const float* const* specs, const int* fram
 }
 
 int gsv_vits_decode(gsv_vits_t* h, const int32_t* codes, int T, const int32_t* phones, int L, const float* noise,
-                    float noise_scale, uint64_t seed, float* wav, gsv_stream_t stream) {
+                    float noise_scale, float speed, uint64_t seed, float* wav, gsv_stream_t stream) {
   GSV_REQUIRE(h && h->finalized, "vits_decode: handle not finalized");
   GSV_REQUIRE(h->has_ref, "vits_decode: call gsv_vits_set_refer first");
   GSV_REQUIRE(codes && phones && wav && T >= 1 && L >= 1, "vits_decode: empty input (T=%d, L=%d)", T, L);
@@ -747,42 +819,52 @@ int gsv_vits_decode(gsv_vits_t* h, const int32_t* codes, int T, const int32_t* p
   const auto& c = h->cfg;
   const size_t es = esz(h);
   const int H = c.hidden_channels, IC = c.inter_channels, SSL = c.ssl_dim, MH = 512;
-  const int F = 2 * T;
+  const int F0 = 2 * T;
+  GSV_REQUIRE(speed > 0.f, "vits_decode: speed must be positive");
+  const int F = (speed == 1.f) ? F0 : (int)((float)F0 / speed) + 1;   // frames after the speed interpolation
   GSV_HIP(hipEventRecord(h->ev[0], s));
   // ---- H8: codebook gather + nearest x2
   void *q768, *y, *tx;
-  GSV_RC(need(h, "q768", (size_t)F * SSL * es, &q768));
-  GSV_RC(need(h, "enc_x", (size_t)F * H * es, &y));
+  GSV_RC(need(h, "q768", (size_t)F0 * SSL * es, &q768));
+  GSV_RC(need(h, "enc_x", (size_t)F0 * H * es, &y));
   GSV_RC(need(h, "enc_tx", (size_t)L * H * es, &tx));
   GSV_DISPATCH(h,
-    hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(F), dim3(128), 0, s, codes, h->codebook, SSL, 2, T, (_Float16*)q768),
-    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(F), dim3(128), 0, s, codes, h->codebook, SSL, 2, T, (float*)q768));
+    hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(F0), dim3(128), 0, s, codes, h->codebook, SSL, 2, T, (_Float16*)q768),
+    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(F0), dim3(128), 0, s, codes, h->codebook, SSL, 2, T, (float*)q768));
   // ---- H10: enc_p
   ConvOpt o;
-  GSV_RC(conv(h, s, h->ssl_proj_enc, q768, SSL, F, y, F, o));
-  GSV_RC(run_encoder(h, s, h->enc_ssl, y, F));
+  GSV_RC(conv(h, s, h->ssl_proj_enc, q768, SSL, F0, y, F0, o));
+  GSV_RC(run_encoder(h, s, h->enc_ssl, y, F0));
   GSV_DISPATCH(h,
     hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(L), dim3(128), 0, s, phones, h->text_emb, H, 1, L, (_Float16*)tx),
     hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(L), dim3(128), 0, s, phones, h->text_emb, H, 1, L, (float*)tx));
   GSV_RC(run_encoder(h, s, h->enc_text, tx, L));
   {  // MRTE (mrte_model.py:25-44)
     void *s512, *t512, *q512, *kv512, *o512, *x512;
-    GSV_RC(need(h, "m_s", (size_t)F * MH * es, &s512));
+    GSV_RC(need(h, "m_s", (size_t)F0 * MH * es, &s512));
     GSV_RC(need(h, "m_t", (size_t)L * MH * es, &t512));
-    GSV_RC(need(h, "m_q", (size_t)F * MH * es, &q512));
+    GSV_RC(need(h, "m_q", (size_t)F0 * MH * es, &q512));
     GSV_RC(need(h, "m_kv", (size_t)L * 2 * MH * es, &kv512));
-    GSV_RC(need(h, "m_o", (size_t)F * MH * es, &o512));
-    GSV_RC(need(h, "m_x", (size_t)F * MH * es, &x512));
-    GSV_RC(conv(h, s, h->c_pre, y, H, F, s512, F, o));
+    GSV_RC(need(h, "m_o", (size_t)F0 * MH * es, &o512));
+    GSV_RC(need(h, "m_x", (size_t)F0 * MH * es, &x512));
+    GSV_RC(conv(h, s, h->c_pre, y, H, F0, s512, F0, o));
     GSV_RC(conv(h, s, h->text_pre, tx, H, L, t512, L, o));
-    GSV_RC(conv(h, s, h->mq, s512, MH, F, q512, F, o));
+    GSV_RC(conv(h, s, h->mq, s512, MH, F0, q512, F0, o));
     GSV_RC(conv(h, s, h->mkv, t512, MH, L, kv512, L, o));
-    GSV_RC(attention(h, s, q512, MH, 0, kv512, 2 * MH, 0, MH, F, L, 4, MH / 4, 1.f / sqrtf((float)(MH / 4)), nullptr, nullptr, o512, MH));
+    GSV_RC(attention(h, s, q512, MH, 0, kv512, 2 * MH, 0, MH, F0, L, 4, MH / 4, 1.f / sqrtf((float)(MH / 4)), nullptr, nullptr, o512, MH));
     ConvOpt om; om.res = s512; om.ldr = MH; om.bias_override = h->mo_bias_eff;
-    GSV_RC(conv(h, s, h->mo, o512, MH, F, x512, F, om));
-    GSV_RC(conv(h, s, h->c_post, x512, MH, F, y, F, o));
+    GSV_RC(conv(h, s, h->mo, o512, MH, F0, x512, F0, om));
+    GSV_RC(conv(h, s, h->c_post, x512, MH, F0, y, F0, o));
   }
-  GSV_RC(run_encoder(h, s, h->enc2, y, F));
+  GSV_RC(run_encoder(h, s, h->enc2, y, F0));
+  if (F != F0) {
+    void* yi;
+    GSV_RC(need(h, "enc_x_speed", (size_t)F * H * es, &yi));
+    GSV_DISPATCH(h,
+      hipLaunchKernelGGL(interp_linear_kernel<_Float16>, dim3(F), dim3(64), 0, s, (const _Float16*)y, F0, F, H, (_Float16*)yi),
+      hipLaunchKernelGGL(interp_linear_kernel<float>, dim3(F), dim3(64), 0, s, (const float*)y, F0, F, H, (float*)yi));
+    y = yi;
+  }
   float* stats;
   GSV_RC(need(h, "stats", (size_t)F * 2 * IC * 4, (void**)&stats));
   { ConvOpt of; of.out_f32 = 1; GSV_RC(conv(h, s, h->proj, y, H, F, stats, F, of)); }
@@ -941,6 +1023,231 @@ int gsv_vits_debug_tensor(gsv_vits_t* h, const char* name, float* out, int64_t c
     return GSV_ERR_ARG;
   }
   GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+}  // extern "C"
+
+// =======================================================================================
+// Vocoders of the v3/v4 path: v4 = the HiFi-GAN `Generator` used as a mel vocoder (H16, reference
+// TTS_infer_pack/TTS.py:631-648, module/models.py:407-471), v3 = BigVGAN-v2 (H15, reference
+// BigVGAN/bigvgan.py:226-355 with AMPBlock1 :31-131 and anti-aliased SnakeBeta).  Same conv kernels
+// and channels-last layout as the v2 generator above; mel channels are zero-padded to a multiple of 8.
+// =======================================================================================
+struct VocAct { float *alpha = nullptr, *beta = nullptr; };
+
+struct gsv_vocoder {
+  gsv_vits ctx;               // reused as the allocation / staging / workspace context of the helpers above
+  gsv_vocoder_config cfg;
+  int cin_pad = 0;
+  Conv conv_pre, conv_post;
+  std::vector<Conv> ups, rb1, rb2;
+  std::vector<VocAct> acts;   // BigVGAN: [stage][block][6] + final
+  float *up12 = nullptr, *dn12 = nullptr;
+  bool finalized = false;
+};
+
+namespace {
+
+// Conv1d weight [cout][cin][k] with the input channels zero-padded to cin_pad
+int make_conv_padded(gsv_vits* h, const std::string& name, int cout, int cin, int cin_pad, int k, bool bias, Conv* c) {
+  std::vector<float> w, b;
+  if (!fetch(h, name + ".weight", (size_t)cout * cin * k, cout, w)) return GSV_ERR_ARG;
+  std::vector<float> p((size_t)cout * k * cin_pad, 0.f);
+  for (int o = 0; o < cout; ++o)
+    for (int i = 0; i < cin; ++i)
+      for (int j = 0; j < k; ++j) p[((size_t)o * k + j) * cin_pad + i] = w[((size_t)o * cin + i) * k + j];
+  GSV_RC(up_t(h, p, &c->w));
+  if (bias) {
+    if (!fetch(h, name + ".bias", cout, cout, b)) return GSV_ERR_ARG;
+    GSV_RC(up_f32(h, b.data(), b.size(), &c->b));
+  }
+  c->cin = cin_pad; c->cout = cout; c->taps = k;
+  return GSV_OK;
+}
+
+// Kaiser-windowed sinc low-pass of BigVGAN's Activation1d (filter.py:30-60), cutoff 0.25, half-width 0.3, 12 taps
+void kaiser_sinc12(float* out) {
+  const int K = 12, half = 6;
+  const double cutoff = 0.25, hw = 0.3;
+  const double A = 2.285 * (half - 1) * M_PI * 4 * hw + 7.95;
+  const double beta = A > 50.0 ? 0.1102 * (A - 8.7) : (A >= 21.0 ? 0.5842 * pow(A - 21.0, 0.4) + 0.07886 * (A - 21.0) : 0.0);
+  auto i0 = [](double x) { double s = 1.0, t = 1.0; for (int k = 1; k < 60; ++k) { t *= (x / (2.0 * k)) * (x / (2.0 * k)); s += t; } return s; };
+  double f[12], sum = 0.0;
+  for (int n = 0; n < K; ++n) {
+    const double r = 2.0 * n / (K - 1) - 1.0;
+    const double win = i0(beta * sqrt(1.0 - r * r)) / i0(beta);
+    const double t = (n - half) + 0.5;
+    const double xx = 2 * cutoff * t;
+    const double sinc = xx == 0.0 ? 1.0 : sin(M_PI * xx) / (M_PI * xx);
+    f[n] = 2 * cutoff * win * sinc;
+    sum += f[n];
+  }
+  for (int n = 0; n < K; ++n) out[n] = (float)(f[n] / sum);
+}
+
+int voc_act(gsv_vocoder* v, hipStream_t s, const VocAct& a, const void* x, void* y, int Tn, int C) {
+  gsv_vits* h = &v->ctx;
+  dim3 grid(cdiv(Tn, 64), cdiv(C, 64));
+  GSV_DISPATCH(h,
+    hipLaunchKernelGGL(aa_act_cl_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)x, (_Float16*)y, Tn, C, C, a.alpha, a.beta,
+                       v->cfg.snake_logscale, v->up12, v->dn12),
+    hipLaunchKernelGGL(aa_act_cl_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, Tn, C, C, a.alpha, a.beta,
+                       v->cfg.snake_logscale, v->up12, v->dn12));
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsv_vocoder_create(const gsv_vocoder_config* cfg, int dtype, gsv_vocoder_t** out) {
+  GSV_REQUIRE(cfg && out, "vocoder_create: null argument");
+  GSV_REQUIRE(dtype == GSV_F16 || dtype == GSV_F32, "vocoder_create: bad dtype");
+  GSV_REQUIRE(cfg->n_ups >= 1 && cfg->n_ups <= 8 && cfg->n_resblocks >= 1 && cfg->n_resblocks <= 4, "vocoder_create: bad shape");
+  GSV_REQUIRE(cfg->kind == 0 || cfg->kind == 1, "vocoder_create: kind must be 0 (HiFi-GAN) or 1 (BigVGAN)");
+  GSV_REQUIRE((cfg->upsample_initial_channel >> cfg->n_ups) % 8 == 0, "vocoder_create: final channel count must be a multiple of 8");
+  int n = 0;
+  GSV_HIP(hipGetDeviceCount(&n));
+  gsv_vocoder* v = new gsv_vocoder();
+  v->cfg = *cfg;
+  v->ctx.dtype = dtype;
+  v->cin_pad = (cfg->in_channels + 7) / 8 * 8;
+  *out = v;
+  return GSV_OK;
+}
+
+void gsv_vocoder_destroy(gsv_vocoder_t* v) {
+  if (!v) return;
+  for (void* p : v->ctx.allocs) (void)hipFree(p);
+  for (auto& b : v->ctx.bufs) if (b.second.p) (void)hipFree(b.second.p);
+  delete v;
+}
+
+int gsv_vocoder_load_tensor(gsv_vocoder_t* v, const char* name, const float* data, int64_t numel) {
+  GSV_REQUIRE(v && name && data && numel > 0, "vocoder_load_tensor: bad argument");
+  GSV_REQUIRE(!v->finalized, "vocoder_load_tensor: handle already finalized");
+  v->ctx.staged[name].assign(data, data + numel);
+  return GSV_OK;
+}
+
+int gsv_vocoder_finalize(gsv_vocoder_t* v) {
+  GSV_REQUIRE(v && !v->finalized, "vocoder_finalize: bad handle");
+  gsv_vits* h = &v->ctx;
+  const auto& c = v->cfg;
+  const int UIC = c.upsample_initial_channel;
+  const bool big = c.kind == 1;
+  GSV_RC(make_conv_padded(h, "conv_pre", UIC, c.in_channels, v->cin_pad, 7, true, &v->conv_pre));
+  v->ups.resize(c.n_ups);
+  int ch = UIC;
+  auto load_act = [&](const std::string& prefix, int C, VocAct* a) -> int {
+    GSV_RC(make_vec(h, prefix + ".alpha", C, &a->alpha));
+    if (h->staged.count(prefix + ".beta")) { GSV_RC(make_vec(h, prefix + ".beta", C, &a->beta)); }
+    else a->beta = a->alpha;   // Snake: one parameter for both (activation1d.py:58-61)
+    return GSV_OK;
+  };
+  for (int i = 0; i < c.n_ups; ++i) {
+    const int cin = UIC >> i, cout = UIC >> (i + 1);
+    const std::string un = big ? "ups." + std::to_string(i) + ".0" : "ups." + std::to_string(i);
+    GSV_RC(make_ups(h, un, cin, cout, c.up_kernels[i], c.up_rates[i], &v->ups[i]));
+    ch = cout;
+    for (int j = 0; j < c.n_resblocks; ++j) {
+      const std::string r = "resblocks." + std::to_string(i * c.n_resblocks + j);
+      for (int k = 0; k < 3; ++k) {
+        Conv c1, c2;
+        GSV_RC(make_conv(h, r + ".convs1." + std::to_string(k), ch, ch, c.rb_kernels[j], true, &c1));
+        GSV_RC(make_conv(h, r + ".convs2." + std::to_string(k), ch, ch, c.rb_kernels[j], true, &c2));
+        v->rb1.push_back(c1);
+        v->rb2.push_back(c2);
+      }
+      if (big)
+        for (int k = 0; k < 6; ++k) {
+          VocAct a;
+          GSV_RC(load_act(r + ".activations." + std::to_string(k) + ".act", ch, &a));
+          v->acts.push_back(a);
+        }
+    }
+  }
+  if (big) {
+    VocAct a;
+    GSV_RC(load_act("activation_post.act", ch, &a));
+    v->acts.push_back(a);
+    float f[12];
+    kaiser_sinc12(f);
+    GSV_RC(up_f32(h, f, 12, &v->up12));
+    GSV_RC(up_f32(h, f, 12, &v->dn12));
+  }
+  GSV_RC(make_conv(h, "conv_post", 1, ch, 7, c.bias_at_final != 0, &v->conv_post));
+  h->staged.clear();
+  h->finalized = true;
+  v->finalized = true;
+  return GSV_OK;
+}
+
+int gsv_vocoder_forward(gsv_vocoder_t* v, const float* mel, int F, float* wav, gsv_stream_t stream) {
+  GSV_REQUIRE(v && v->finalized, "vocoder_forward: handle not finalized");
+  GSV_REQUIRE(mel && wav && F >= 1, "vocoder_forward: empty input");
+  hipStream_t s = (hipStream_t)stream;
+  gsv_vits* h = &v->ctx;
+  const auto& c = v->cfg;
+  const size_t es = esz(h);
+  const bool big = c.kind == 1;
+  const int UIC = c.upsample_initial_channel;
+  size_t maxel = (size_t)F * UIC;
+  {
+    long long Tn = F; int ch = UIC;
+    for (int i = 0; i < c.n_ups; ++i) { Tn *= c.up_rates[i]; ch >>= 1; maxel = std::max(maxel, (size_t)Tn * ch); }
+  }
+  void* xin;
+  GSV_RC(need(h, "voc_in", (size_t)F * v->cin_pad * es, &xin));
+  GSV_HIP(hipMemsetAsync(xin, 0, (size_t)F * v->cin_pad * es, s));
+  GSV_DISPATCH(h,
+    hipLaunchKernelGGL(cf_to_cl_kernel<_Float16>, dim3(cdiv(F, 32), cdiv(c.in_channels, 32)), dim3(256), 0, s, mel, F, c.in_channels, (_Float16*)xin, v->cin_pad),
+    hipLaunchKernelGGL(cf_to_cl_kernel<float>, dim3(cdiv(F, 32), cdiv(c.in_channels, 32)), dim3(256), 0, s, mel, F, c.in_channels, (float*)xin, v->cin_pad));
+  void* gb[6];
+  const char* gnames[6] = {"v0", "v1", "v2", "v3", "v4", "v5"};
+  for (int i = 0; i < 6; ++i) GSV_RC(need(h, gnames[i], maxel * es, &gb[i]));
+  void* cur = gb[3];
+  { ConvOpt o; GSV_RC(conv(h, s, v->conv_pre, xin, v->cin_pad, F, cur, F, o)); }
+  int Tn = F, ch = UIC, ai = 0;
+  for (int i = 0; i < c.n_ups; ++i) {
+    const int Tout = Tn * c.up_rates[i];
+    ch >>= 1;
+    void* xup = gb[0]; void* xt = gb[1]; void* R = gb[2]; void* xa = gb[5]; void* xs = (cur == gb[3]) ? gb[4] : gb[3];
+    { ConvOpt ou; if (!big) { ou.pre_act = ACT_LRELU; ou.pre_slope = 0.1f; }
+      GSV_RC(conv(h, s, v->ups[i], cur, ch * 2, Tn, xup, Tout, ou)); }
+    for (int j = 0; j < c.n_resblocks; ++j) {
+      const void* xr = xup;
+      for (int k = 0; k < 3; ++k) {
+        const Conv& c1 = v->rb1[(i * c.n_resblocks + j) * 3 + k];
+        const Conv& c2 = v->rb2[(i * c.n_resblocks + j) * 3 + k];
+        ConvOpt o1; o1.dil = c.rb_dilations[j][k];
+        ConvOpt o2; o2.res = xr; o2.ldr = ch;
+        const void* in1 = xr;
+        if (big) { GSV_RC(voc_act(v, s, v->acts[ai + 2 * k], xr, xa, Tout, ch)); in1 = xa; }
+        else { o1.pre_act = ACT_LRELU; o1.pre_slope = 0.1f; o2.pre_act = ACT_LRELU; o2.pre_slope = 0.1f; }
+        GSV_RC(conv(h, s, c1, in1, ch, Tout, xt, Tout, o1));
+        const void* in2 = xt;
+        if (big) { GSV_RC(voc_act(v, s, v->acts[ai + 2 * k + 1], xt, xa, Tout, ch)); in2 = xa; }
+        if (k < 2) {
+          GSV_RC(conv(h, s, c2, in2, ch, Tout, R, Tout, o2));
+          xr = R;
+        } else {
+          o2.scale = 1.f / (float)c.n_resblocks; o2.accumulate = j > 0;
+          GSV_RC(conv(h, s, c2, in2, ch, Tout, xs, Tout, o2));
+        }
+      }
+      if (big) ai += 6;
+    }
+    cur = xs; Tn = Tout;
+  }
+  ConvOpt op; op.out_f32 = 1;
+  const void* pin = cur;
+  if (big) { GSV_RC(voc_act(v, s, v->acts[ai], cur, gb[5], Tn, ch)); pin = gb[5]; }
+  else { op.pre_act = ACT_LRELU; op.pre_slope = 0.01f; }
+  op.post_act = c.tanh_at_final ? ACT_TANH : ACT_CLAMP1;
+  GSV_RC(conv(h, s, v->conv_post, pin, ch, Tn, wav, Tn, op));
   return GSV_OK;
 }
 

@@ -29,6 +29,13 @@ class VitsConfig(C.Structure):
                 ("rb_kernels", C.c_int * 4), ("rb_dilations", (C.c_int * 3) * 4), ("ref_bins", C.c_int)]
 
 
+class VocoderConfig(C.Structure):
+    _fields_ = [("kind", C.c_int), ("in_channels", C.c_int), ("upsample_initial_channel", C.c_int), ("n_ups", C.c_int),
+                ("up_rates", C.c_int * 8), ("up_kernels", C.c_int * 8), ("n_resblocks", C.c_int),
+                ("rb_kernels", C.c_int * 4), ("rb_dilations", (C.c_int * 3) * 4), ("bias_at_final", C.c_int),
+                ("tanh_at_final", C.c_int), ("snake_logscale", C.c_int)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("res", C.c_void_p),
                 ("T_in", C.c_int), ("T_out", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("taps", C.c_int),
@@ -59,11 +66,16 @@ _SIGS = {
     "gsv_vits_set_refer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                      C.c_void_p]),
     "gsv_vits_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
-                                  C.c_uint64, C.c_void_p, C.c_void_p]),
+                                  C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
     "gsv_vits_extract_latent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gsv_vits_debug_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
                                         C.c_void_p]),
     "gsv_vits_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "gsv_vocoder_create": (C.c_int, [C.POINTER(VocoderConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    "gsv_vocoder_destroy": (None, [C.c_void_p]),
+    "gsv_vocoder_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "gsv_vocoder_finalize": (C.c_int, [C.c_void_p]),
+    "gsv_vocoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gsv_aa_act_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gsv_op_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),

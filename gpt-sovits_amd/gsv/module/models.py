@@ -115,9 +115,6 @@ class SynthesizerTrn:
         `noise` (optional, [inter, 2T]) injects the randn_like draw of models.py:1000 for parity tests."""
         if not self._loaded:
             raise RuntimeError("load_state_dict() first")
-        if speed != 1:
-            raise NotImplementedError("speed != 1 (linear interpolation of enc_p output, models.py:226-228) "
-                                      "is not built yet")
         if sv_emb is not None:
             raise NotImplementedError("v2Pro speaker-verification conditioning is out of scope (SURVEY section 8f N4)")
         if codes.numel() == 0 or text.numel() == 0:
@@ -130,13 +127,14 @@ class SynthesizerTrn:
             self._set_refer(refer)
             cd = codes.reshape(-1).to(self.device, torch.int32).contiguous()
             tx = text.reshape(-1).to(self.device, torch.int32).contiguous()
+            frames = 2 * T if speed == 1 else int(2 * T / speed) + 1      # models.py:226-228
             nz = None
             if noise is not None:
-                nz = noise.reshape(self.inter_channels, 2 * T).to(self.device, torch.float32).contiguous()
-            wav = torch.empty(2 * T * up, dtype=torch.float32, device=self.device)
+                nz = noise.reshape(self.inter_channels, frames).to(self.device, torch.float32).contiguous()
+            wav = torch.empty(frames * up, dtype=torch.float32, device=self.device)
             _lib.check(_lib.lib().gsv_vits_decode(self._h, cd.data_ptr(), T, tx.data_ptr(), L,
                                                   nz.data_ptr() if nz is not None else None, float(noise_scale),
-                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, wav.data_ptr(),
+                                                  float(speed), int(seed) & 0xFFFFFFFFFFFFFFFF, wav.data_ptr(),
                                                   C.c_void_p(self.stream.cuda_stream)), "gsv_vits_decode")
             self.stream.synchronize()
         return wav.to(self.dtype).view(1, 1, -1)
@@ -171,3 +169,36 @@ class SynthesizerTrn:
         a, b = C.c_float(0), C.c_float(0)
         _lib.check(_lib.lib().gsv_vits_last_timing(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+
+class Generator:
+    """Host-side mirror of the reference's HiFi-GAN `Generator` used as the v4 mel vocoder
+    (reference module/models.py:407-471; constructed in TTS_infer_pack/TTS.py:631-648 with
+    initial_channel=100, rates (10,6,2,2,2), kernels (20,12,4,4,4), gin_channels=0, is_bias=True)."""
+
+    def __init__(self, initial_channel, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, gin_channels=0, is_bias=False, device="cuda:0",
+                 dtype=torch.float16):
+        from .vocoder import _VocoderEngine
+        if str(resblock) != "1":
+            raise NotImplementedError("only ResBlock1 generators")
+        if gin_channels != 0:
+            raise NotImplementedError("the conditioned generator is part of SynthesizerTrn.decode")
+        self._e = _VocoderEngine(0, initial_channel, upsample_initial_channel, upsample_rates, upsample_kernel_sizes,
+                                 resblock_kernel_sizes, resblock_dilation_sizes, bias_at_final=is_bias, tanh_at_final=True,
+                                 snake_logscale=False, device=device, dtype=dtype)
+
+    def load_state_dict(self, sd, strict=True):
+        self._e.load_state_dict(sd, strict)
+        return self
+
+    def remove_weight_norm(self):   # folded at load
+        return self
+
+    def eval(self):
+        return self
+
+    def __call__(self, x, g=None):
+        if g is not None:
+            raise NotImplementedError("conditioning input g")
+        return self._e(x)

@@ -374,3 +374,62 @@ def make_refer_spec(frames: int = 200, bins: int = 1025, seed: int = 0) -> torch
     """Reference spectrogram stand-in uniform[0,1) [1, bins, frames]."""
     u = hash_uniform("refer_spec", bins * frames, seed)
     return torch.from_numpy(u.reshape(1, bins, frames).copy())
+
+
+# --------------------------------------------------------------------------
+# v3 / v4 vocoders (H15, H16)
+# --------------------------------------------------------------------------
+HIFIGAN_V4_CONFIG = {   # reference TTS_infer_pack/TTS.py:631-641
+    "kind": "hifigan", "initial_channel": 100, "resblock": "1", "resblock_kernel_sizes": [3, 7, 11],
+    "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]], "upsample_rates": [10, 6, 2, 2, 2],
+    "upsample_initial_channel": 512, "upsample_kernel_sizes": [20, 12, 4, 4, 4], "gin_channels": 0, "is_bias": True,
+}
+BIGVGAN_V2_24K_CONFIG = {   # reference BigVGAN/configs/bigvgan_v2_24khz_100band_256x.json
+    "kind": "bigvgan", "num_mels": 100, "resblock": "1", "resblock_kernel_sizes": [3, 7, 11],
+    "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]], "upsample_rates": [4, 4, 2, 2, 2, 2],
+    "upsample_kernel_sizes": [8, 8, 4, 4, 4, 4], "upsample_initial_channel": 1536, "activation": "snakebeta",
+    "snake_logscale": True, "use_tanh_at_final": False, "use_bias_at_final": False,
+}
+
+
+def small_vocoder_config(kind: str):
+    base = dict(HIFIGAN_V4_CONFIG if kind == "hifigan" else BIGVGAN_V2_24K_CONFIG)
+    base.update({"upsample_rates": [4, 2, 2], "upsample_kernel_sizes": [8, 4, 4], "upsample_initial_channel": 128})
+    return base
+
+
+def make_vocoder_state_dict(cfg: dict, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """Plain (weight-norm removed) state dict, as the reference holds the vocoders at inference
+    (TTS.py:615,642 call remove_weight_norm())."""
+    big = cfg["kind"] == "bigvgan"
+    cin = cfg["num_mels"] if big else cfg["initial_channel"]
+    UIC = cfg["upsample_initial_channel"]
+    sd = OrderedDict()
+    sd["conv_pre.weight"] = _w("voc.conv_pre.weight", (UIC, cin, 7), cin * 7, 1.0, seed)
+    sd["conv_pre.bias"] = _b("voc.conv_pre.bias", UIC, 0.05, seed)
+    ch = UIC
+    nk = len(cfg["resblock_kernel_sizes"])
+    for i, (u, k) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
+        ci, co = UIC // (2 ** i), UIC // (2 ** (i + 1))
+        un = f"ups.{i}.0" if big else f"ups.{i}"
+        sd[un + ".weight"] = _w(f"voc.{un}.weight", (ci, co, k), ci * max(k // u, 1), 1.0, seed)
+        sd[un + ".bias"] = _b(f"voc.{un}.bias", co, 0.05, seed)
+        ch = co
+        for j, rk in enumerate(cfg["resblock_kernel_sizes"]):
+            r = f"resblocks.{i * nk + j}"
+            for c in range(3):
+                for nm in ("convs1", "convs2"):
+                    sd[f"{r}.{nm}.{c}.weight"] = _w(f"voc.{r}.{nm}.{c}.weight", (ch, ch, rk), ch * rk, 0.7, seed)
+                    sd[f"{r}.{nm}.{c}.bias"] = _b(f"voc.{r}.{nm}.{c}.bias", ch, 0.05, seed)
+            if big:
+                for a in range(6):
+                    sd[f"{r}.activations.{a}.act.alpha"] = hash_symmetric(f"voc.{r}.act{a}.alpha", (ch,), 0.5, seed)
+                    sd[f"{r}.activations.{a}.act.beta"] = hash_symmetric(f"voc.{r}.act{a}.beta", (ch,), 0.5, seed)
+    if big:
+        sd["activation_post.act.alpha"] = hash_symmetric("voc.post.alpha", (ch,), 0.5, seed)
+        sd["activation_post.act.beta"] = hash_symmetric("voc.post.beta", (ch,), 0.5, seed)
+        sd["conv_post.weight"] = _w("voc.conv_post.weight", (1, ch, 7), ch * 7, 0.05, seed)
+    else:
+        sd["conv_post.weight"] = _w("voc.conv_post.weight", (1, ch, 7), ch * 7, 0.3, seed)
+        sd["conv_post.bias"] = _b("voc.conv_post.bias", 1, 0.05, seed)
+    return sd

@@ -124,11 +124,12 @@ int gsv_vits_finalize(gsv_vits_t* h); /* folds weight-norm, repacks conv weights
  * of n_refs [dev] fp32 pointers, each [bins][frames[i]] channels-first as the reference holds it. */
 int gsv_vits_set_refer(gsv_vits_t* h, const float* const* specs, const int* frames, int bins, int n_refs,
                        gsv_stream_t stream);
-/* codes [dev] int32 [T], phones [dev] int32 [L], noise [dev] fp32 [inter][2T] channels-first
- * (the randn_like draw of models.py:1000; NULL = counter RNG keyed by seed), wav [dev] fp32
- * [2T * prod(up_rates)]. */
+/* codes [dev] int32 [T], phones [dev] int32 [L]; frames F = 2T when speed == 1, else int(2T/speed)+1
+ * (linear interpolation of the encoder output, models.py:226-228); noise [dev] fp32 [inter][F]
+ * channels-first (the randn_like draw of models.py:1000; NULL = counter RNG keyed by seed),
+ * wav [dev] fp32 [F * prod(up_rates)]. */
 int gsv_vits_decode(gsv_vits_t* h, const int32_t* codes, int T, const int32_t* phones, int L, const float* noise,
-                    float noise_scale, uint64_t seed, float* wav, gsv_stream_t stream);
+                    float noise_scale, float speed, uint64_t seed, float* wav, gsv_stream_t stream);
 /* ssl [dev] fp32 [ssl_dim][T50] channels-first -> codes [dev] int32 [T50/2] */
 int gsv_vits_extract_latent(gsv_vits_t* h, const float* ssl, int T50, int32_t* codes, gsv_stream_t stream);
 /* test hook: copy a named intermediate of the last decode ("ge","m_p","logs_p","z","stage0".."stage4")
@@ -137,6 +138,37 @@ int gsv_vits_debug_tensor(gsv_vits_t* h, const char* name, float* out, int64_t c
                           gsv_stream_t stream);
 /* per-kernel timing hooks for bench.py: device ms of the last decode's generator section */
 int gsv_vits_last_timing(gsv_vits_t* h, float* total_ms, float* generator_ms);
+
+/* ---------------------------------------------------------------------------------------
+ * v3 / v4 vocoders (H15, H16): mel [in_channels][F] -> waveform.
+ *   kind 0 = HiFi-GAN `Generator` as used for v4 (TTS_infer_pack/TTS.py:631-648, module/models.py:407-471:
+ *            leaky-relu 0.1, conv_post bias, tanh); kind 1 = BigVGAN-v2 (BigVGAN/bigvgan.py:226-355:
+ *            AMPBlock1 with anti-aliased Snake/SnakeBeta, clamp or tanh at the end).
+ * Tensor names = the reference state-dict keys (weight-norm pairs or folded weights both accepted).
+ * ------------------------------------------------------------------------------------- */
+typedef struct gsv_vocoder gsv_vocoder_t;
+
+typedef struct {
+  int kind;
+  int in_channels;               /* 100 mel bands */
+  int upsample_initial_channel;
+  int n_ups;
+  int up_rates[8];
+  int up_kernels[8];
+  int n_resblocks;
+  int rb_kernels[4];
+  int rb_dilations[4][3];
+  int bias_at_final;             /* conv_post bias */
+  int tanh_at_final;             /* else clamp to [-1, 1] */
+  int snake_logscale;            /* BigVGAN: alpha/beta stored in log scale */
+} gsv_vocoder_config;
+
+int gsv_vocoder_create(const gsv_vocoder_config* cfg, int dtype, gsv_vocoder_t** out);
+void gsv_vocoder_destroy(gsv_vocoder_t* h);
+int gsv_vocoder_load_tensor(gsv_vocoder_t* h, const char* name, const float* data, int64_t numel);
+int gsv_vocoder_finalize(gsv_vocoder_t* h);
+/* mel [dev] fp32 [in_channels][F] channels-first (as the reference passes it), wav [dev] fp32 [F * prod(up_rates)] */
+int gsv_vocoder_forward(gsv_vocoder_t* h, const float* mel, int F, float* wav, gsv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * BigVGAN anti-aliased snake activation (v3 vocoder), the reference's one native kernel.

@@ -56,6 +56,8 @@ VITS_CASES = {
     "vits_small": dict(cfg="small", seed=2, T=12, L=9, Tr=[30], noise_scale=0.5),
     "vits_small_2ref": dict(cfg="small", seed=4, T=7, L=5, Tr=[24, 17], noise_scale=0.5),
     "vits_v2": dict(cfg="v2", seed=0, T=10, L=8, Tr=[40], noise_scale=0.5),
+    # speed != 1: linear interpolation of the encoder output (reference models.py:226-228)
+    "vits_small_speed": dict(cfg="small", seed=6, T=11, L=7, Tr=[21], noise_scale=0.5, speed=1.3),
 }
 
 
@@ -66,8 +68,28 @@ def vits_case_inputs(case):
     text = torch.from_numpy(S.hash_ints("text", case["L"], cfg["n_symbols"], case["seed"])).view(1, -1)
     refers = [torch.from_numpy(S.hash_uniform(f"refer{i}", 1025 * tr, case["seed"]).reshape(1, 1025, tr).copy())
               for i, tr in enumerate(case["Tr"])]
-    noise = S.hash_normal("vits_noise", (cfg["model"]["inter_channels"], 2 * case["T"]), case["seed"])
+    speed = case.get("speed", 1)
+    frames = 2 * case["T"] if speed == 1 else int(2 * case["T"] / speed) + 1
+    noise = S.hash_normal("vits_noise", (cfg["model"]["inter_channels"], frames), case["seed"])
     ssl = S.hash_symmetric("ssl", (1, 768, 2 * case["T"]), 1.0, case["seed"])
     return cfg, sd, codes, text, refers, noise, ssl
 
 
+
+
+VOC_CASES = {
+    "voc_hifigan_small": dict(kind="hifigan", small=True, seed=1, F=23),
+    "voc_bigvgan_small": dict(kind="bigvgan", small=True, seed=2, F=19),
+    "voc_hifigan_v4": dict(kind="hifigan", small=False, seed=3, F=12),
+    "voc_bigvgan_v2": dict(kind="bigvgan", small=False, seed=4, F=6),
+}
+
+
+def voc_case_inputs(case):
+    if case["small"]:
+        cfg = S.small_vocoder_config(case["kind"])
+    else:
+        cfg = dict(S.HIFIGAN_V4_CONFIG if case["kind"] == "hifigan" else S.BIGVGAN_V2_24K_CONFIG)
+    sd = S.make_vocoder_state_dict(cfg, seed=case["seed"])
+    mel = S.hash_symmetric("voc_mel", (1, 100, case["F"]), 2.0, case["seed"])
+    return cfg, sd, mel

@@ -42,13 +42,14 @@ def gen_vits():
         torch.randn_like = lambda t, **kw: noise.unsqueeze(0).to(t.dtype)
         try:
             with torch.no_grad():
-                ref_wav = model.decode(codes, text, refers, noise_scale=case["noise_scale"])
+                ref_wav = model.decode(codes, text, refers, noise_scale=case["noise_scale"], speed=case.get("speed", 1))
                 ref_codes = model.extract_latent(ssl)
         finally:
             torch.randn_like = orig
         orc = VitsOracle(sd, cfg)
         col = {}
-        wav = orc.decode(codes, text, refers, noise_scale=case["noise_scale"], noise=noise, collect=col)
+        wav = orc.decode(codes, text, refers, noise_scale=case["noise_scale"], noise=noise, collect=col,
+                         speed=case.get("speed", 1))
         ocodes = orc.extract_latent(ssl)
         err = (wav - ref_wav).abs().max().item()
         print(f"[gen_golden] {name}: wav {tuple(ref_wav.shape)} |ref| max {ref_wav.abs().max():.3f} "
@@ -92,3 +93,39 @@ def gen_aa():
         assert err < 1e-5
         np.savez_compressed(os.path.join(GOLD, f"aa_{kind}.npz"), out=ref.numpy(), up_filter=up_f.numpy(),
                             down_filter=dn_f.numpy())
+
+
+def gen_voc():
+    """v4 HiFi-GAN vocoder and v3 BigVGAN: reference classes vs the oracle restatement."""
+    from oracle.cases import VOC_CASES, voc_case_inputs
+    from oracle import vocoder_oracle
+    ref_import.setup()
+    for name, case in VOC_CASES.items():
+        cfg, sd, mel = voc_case_inputs(case)
+        if case["kind"] == "hifigan":
+            from module.models import Generator
+            m = Generator(initial_channel=cfg["initial_channel"], resblock=cfg["resblock"],
+                          resblock_kernel_sizes=cfg["resblock_kernel_sizes"],
+                          resblock_dilation_sizes=cfg["resblock_dilation_sizes"], upsample_rates=cfg["upsample_rates"],
+                          upsample_initial_channel=cfg["upsample_initial_channel"],
+                          upsample_kernel_sizes=cfg["upsample_kernel_sizes"], gin_channels=0, is_bias=True)
+            m.remove_weight_norm()
+            out_o = vocoder_oracle.hifigan(sd, cfg, mel)
+        else:
+            from BigVGAN import bigvgan as rb
+            from BigVGAN.env import AttrDict
+            h = AttrDict({k: v for k, v in cfg.items() if k != "kind"})
+            m = rb.BigVGAN(h)
+            m.remove_weight_norm()
+            out_o = vocoder_oracle.bigvgan(sd, cfg, mel)
+        res = m.load_state_dict(sd, strict=False)
+        bad = [k for k in res.missing_keys if "filter" not in k]
+        assert not bad and not res.unexpected_keys, (bad, res.unexpected_keys)
+        m.eval()
+        with torch.no_grad():
+            ref = m(mel)
+        err = (out_o - ref).abs().max().item()
+        print(f"[gen_golden] {name}: out {tuple(ref.shape)} absmax {ref.abs().max():.3f} rms {ref.pow(2).mean().sqrt():.3f} "
+              f"oracle max-abs err {err:.2e}")
+        assert err <= 1e-4
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), wav=ref.numpy().astype(np.float32))

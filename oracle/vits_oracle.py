@@ -154,13 +154,15 @@ class VitsOracle:
         x = self.conv(o, p + ".cross_attention.conv_o") + s + ge
         return self.conv(x, p + ".c_post")
 
-    def enc_p(self, quantized, text_ids, ge):
+    def enc_p(self, quantized, text_ids, ge, speed=1):
         y = self.conv(quantized, "enc_p.ssl_proj")
         y = self._encoder(y, "enc_p.encoder_ssl", self.n_layers // 2)
         t = self.sd["enc_p.text_embedding.weight"][text_ids].t()
         t = self._encoder(t, "enc_p.encoder_text", self.n_layers)
         y = self._mrte(y, t, ge)
         y = self._encoder(y, "enc_p.encoder2", self.n_layers // 2)
+        if speed != 1:   # models.py:226-228
+            y = F.interpolate(y.unsqueeze(0), size=int(y.shape[-1] / speed) + 1, mode="linear")[0]
         stats = self.conv(y, "enc_p.proj")
         return stats[: self.inter], stats[self.inter:]
 
@@ -222,7 +224,7 @@ class VitsOracle:
     # ---- H7 -------------------------------------------------------------------
     @torch.no_grad()
     def decode(self, codes: torch.Tensor, text: torch.Tensor, refer, noise_scale: float = 0.5,
-               noise: Optional[torch.Tensor] = None, collect: Optional[dict] = None) -> torch.Tensor:
+               noise: Optional[torch.Tensor] = None, collect: Optional[dict] = None, speed: float = 1) -> torch.Tensor:
         """codes [1,1,T] int64, text [1,L] int64, refer: tensor or list of [1,bins,Tr];
         noise: the randn draw of models.py:1000, shape [inter, 2T] (None -> torch RNG).
         Returns [1, 1, 2T*prod(upsample_rates)]."""
@@ -230,7 +232,7 @@ class VitsOracle:
         ge = torch.stack([self.ref_enc(r) for r in refs], 0).mean(0)      # [512, 1]
         q = self.sd["quantizer.vq.layers.0._codebook.embed"][codes[0, 0].long()].t()   # [768, T]
         q = q.repeat_interleave(2, dim=1)                                   # nearest x2
-        m_p, logs_p = self.enc_p(q, text[0].long(), ge)
+        m_p, logs_p = self.enc_p(q, text[0].long(), ge, speed)
         if noise is None:
             noise = torch.randn_like(m_p)
         z_p = m_p + noise * torch.exp(logs_p) * noise_scale

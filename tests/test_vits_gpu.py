@@ -21,7 +21,7 @@ def _engine(cfg, sd, dtype):
     return m
 
 
-@pytest.mark.parametrize("name", ["vits_small", "vits_small_2ref", "vits_v2"])
+@pytest.mark.parametrize("name", ["vits_small", "vits_small_2ref", "vits_v2", "vits_small_speed"])
 def test_fp32_waveform_matches_reference(name):
     """fp32 engine vs the reference's waveform (golden), same injected noise: max-abs <= 1e-4
     (tolerance stated in BASELINE.md section 3); intermediates ge / m_p / z within 1e-4."""
@@ -30,9 +30,9 @@ def test_fp32_waveform_matches_reference(name):
     g = load_golden(name)
     eng = _engine(cfg, sd, torch.float32)
     wav = eng.decode(codes.to(DEV), text.to(DEV), [r.to(DEV) for r in refers], noise_scale=case["noise_scale"],
-                     noise=noise)
+                     noise=noise, speed=case.get("speed", 1))
     assert tuple(wav.shape) == g["wav"].shape
-    IC, F = cfg["model"]["inter_channels"], 2 * case["T"]
+    IC, F = cfg["model"]["inter_channels"], noise.shape[1]
     ge = eng.debug_tensor("ge", 512).cpu().numpy()
     assert np.abs(ge - g["ge"].reshape(-1)).max() < 1e-4
     m_p = eng.debug_tensor("m_p", IC * F).cpu().numpy().reshape(IC, F)
@@ -113,3 +113,34 @@ def test_aa_activation_shapes_and_edges():
     empty = aa.forward(torch.zeros(2, 3, 0, device=DEV), uf.view(1, 1, 12).to(DEV), df.view(1, 1, 12).to(DEV),
                        torch.zeros(3, device=DEV), torch.zeros(3, device=DEV))
     assert empty.shape == (2, 3, 0)
+
+
+def _vocoder(cfg, sd, dtype):
+    if cfg["kind"] == "hifigan":
+        from gsv.module.models import Generator
+        m = Generator(initial_channel=cfg["initial_channel"], resblock=cfg["resblock"],
+                      resblock_kernel_sizes=cfg["resblock_kernel_sizes"],
+                      resblock_dilation_sizes=cfg["resblock_dilation_sizes"], upsample_rates=cfg["upsample_rates"],
+                      upsample_initial_channel=cfg["upsample_initial_channel"],
+                      upsample_kernel_sizes=cfg["upsample_kernel_sizes"], gin_channels=0, is_bias=True, device=DEV, dtype=dtype)
+    else:
+        from gsv.BigVGAN.bigvgan import BigVGAN
+        m = BigVGAN({k: v for k, v in cfg.items() if k != "kind"}, device=DEV, dtype=dtype)
+    m.load_state_dict(sd)
+    return m
+
+
+@pytest.mark.parametrize("name", ["voc_hifigan_small", "voc_bigvgan_small", "voc_hifigan_v4", "voc_bigvgan_v2"])
+def test_vocoders_match_reference(name):
+    """v4 HiFi-GAN vocoder (H16) and v3 BigVGAN (H15) vs the reference classes' output (golden):
+    fp32 engine max-abs <= 2e-4; fp16 engine max-abs <= 3e-2 and relative RMS <= 5 %."""
+    case = cases.VOC_CASES[name]
+    cfg, sd, mel = cases.voc_case_inputs(case)
+    g = load_golden(name)["wav"]
+    out = _vocoder(cfg, sd, torch.float32)(mel.to(DEV)).float().cpu().numpy()
+    assert out.shape == g.shape
+    assert np.abs(out - g).max() <= 2e-4
+    out16 = _vocoder(cfg, sd, torch.float16)(mel.to(DEV)).float().cpu().numpy()
+    err = out16 - g
+    assert np.abs(err).max() <= 3e-2
+    assert np.sqrt((err ** 2).mean()) <= 0.05 * np.sqrt((g ** 2).mean())
