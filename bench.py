@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--cpu-utts", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="parity dtype (not the benchmark configuration)")
+    ap.add_argument("--pyprofile", action="store_true", help="cProfile one extra step (host-side hot spots)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,7 +134,7 @@ def main():
         for sr, audio in tts.run(dict(params, segments=segments)):
             out = audio
         tok_count[0] += tts.last_generated_tokens
-        return torch.from_numpy(out).to(dev), list(tts.last_fragment_lengths)
+        return out, list(tts.last_fragment_lengths)
 
     sh = ShardedSynthesizer(synth, dev)
 
@@ -143,6 +144,11 @@ def main():
     for i in range(args.warmup):
         step()
         log(f"warmup {i} done")
+    if args.pyprofile:
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable(); step(); torch.cuda.synchronize(); pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(35)
     tok_count[0] = 0
     times = []
     if world > 1:
@@ -185,6 +191,16 @@ def main():
                 "note": "one launch = one layer's K+V arena for all rows at the end-of-run cache length; "
                         "HIP events on the engine stream around 10x24 back-to-back launches over the 24 layers' "
                         "distinct arenas (24 x 18 MB > Infinity Cache: every launch streams from HBM), rows forced active"}
+        # single-utterance latency (BASELINE configs[0] shape on the GPU): median of 5 one-sentence runs
+        lat = []
+        for _ in range(6):
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _sr, _a in tts.run(dict(params, batch_size=1, segments=segs_all[:1])):
+                pass
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - ts)
+        lat_b1 = statistics.median(lat[1:])
         res = {
             "metric": "synthesised audio sec/sec (1/RTF), v2 pipeline", "value": round(audio_s / elapsed, 2),
             "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,6 +211,7 @@ def main():
                                    "random-init v2 weights", "utterances_per_gpu": B, "tokens_per_utterance": TOK,
                        "parallelism": f"utterance-sharded x{world}"},
             "p50_utterance_latency_ms": round(1e3 * statistics.median(times), 2),
+            "p50_single_utterance_latency_ms": round(1e3 * lat_b1, 2),
             "rtf": round(elapsed / audio_s, 6),
             "stage_ms_last_step": {"to_batch": round(1e3 * t_batch, 2), "ar_t34": round(1e3 * t_ar, 2),
                                    "sovits_decode_t45": round(1e3 * t_dec, 2), "sovits_device": round(vt_total, 2),

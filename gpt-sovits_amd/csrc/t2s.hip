@@ -12,6 +12,7 @@
 // fused into the consumer's prologue, split-K across the waves of a workgroup with an LDS
 // combine (no global partials), then logits + a one-wave-per-row sampling kernel.
 #include <math.h>
+#include <stdlib.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 16;
+  const int b0 = blockIdx.y * CB * 16;   // batch-row block of this workgroup (grid.y > 1 only for narrow-N kernels)
   const int K = a.K;
   const int ldx = K + G;  // padded LDS row (elements): breaks the power-of-two row stride
   T* xs = (T*)smem;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
   for (int it = 0; it < ITEMS; ++it) {
     const int item = tid + it * NW * 64;
     const int ln = item & 63;
-    const int b = (item >> 6) * 16 + (ln & 15);
+    const int b = b0 + (item >> 6) * 16 + (ln & 15);
     const int n = n0 + 4 * (ln >> 4);
     const bool ok = item < CB * 64 && b < a.B && n < a.N;
     pre_bias[it] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -267,9 +269,9 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
     for (int r0 = 0; r0 < CB * 16; r0 += RPP) {
       const int row = r0 + tid / TPR;
       if (row >= CB * 16) break;
-      const bool live = row < a.B;
+      const bool live = b0 + row < a.B;
       f4 v[NV];
-      const float* src = a.yin + (long long)(live ? row : 0) * K;
+      const float* src = a.yin + (long long)(live ? b0 + row : 0) * K;
 #pragma unroll
       for (int j = 0; j < NV; ++j) v[j] = live ? *(const f4*)(src + (j * TPR + sub) * 4) : (f4){0.f, 0.f, 0.f, 0.f};
       if (a.gamma) {
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
       for (int j = 0; j < NV; ++j) {
         typedef T T4 __attribute__((ext_vector_type(4)));
         *(T4*)(dst + (j * TPR + sub) * 4) = (T4){(T)v[j][0], (T)v[j][1], (T)v[j][2], (T)v[j][3]};
-        if (a.xres_out && blockIdx.x == 0 && live) *(f4*)(a.xres_out + (long long)row * K + (j * TPR + sub) * 4) = v[j];
+        if (a.xres_out && blockIdx.x == 0 && live) *(f4*)(a.xres_out + (long long)(b0 + row) * K + (j * TPR + sub) * 4) = v[j];
       }
     }
     __syncthreads();
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
     for (int cb = 0; cb < CB; ++cb) {
       const int brow = cb * 16 + rowl;
       if (LNPRO) bf[i][cb] = *(const F*)(xs + (long long)brow * ldx + k);
-      else if (brow < a.B) bf[i][cb] = *(const F*)(xg + (long long)brow * K + k);
+      else if (b0 + brow < a.B) bf[i][cb] = *(const F*)(xg + (long long)(b0 + brow) * K + k);
       else {
 #pragma unroll
         for (int e = 0; e < G; ++e) bf[i][cb][e] = 0;
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
     f4v v = (f4v){0.f, 0.f, 0.f, 0.f};
     for (int w = 0; w < NW; ++w) v += *(const f4v*)(red + ((w * CB + cb) * 64 + ln) * 4);
     // D layout of 16x16: col = ln & 15 (batch row), rows 4*(ln>>4) + i (output channel)
-    const int b = cb * 16 + (ln & 15);
+    const int b = b0 + cb * 16 + (ln & 15);
     const int n = n0 + 4 * (ln >> 4);
     if (b >= a.B || n >= a.N) continue;
     float o[4];
@@ -507,6 +509,244 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
+// Fused decode kernel A = LayerNorm prologue + QKV projection of ONE head + in-place KV append +
+// attention over the cached keys, for RPG = 2 batch rows per workgroup (grid = heads x rows/2 = 256
+// workgroups at B = 32: one per CU).  It replaces the separate QKV and attention launches: the
+// K/V stream of the (row, head) pairs is requested at kernel entry (speculatively, before kv_len is
+// known) so the HBM latency of the cache overlaps the weight fetch, the LayerNorm and the MFMAs.
+//   waves 0,1 -> row 0, waves 2,3 -> row 1 for the attention; all 4 waves split K for the projection.
+// ---------------------------------------------------------------------------------------
+struct QkvAttnArgs {
+  const float* yin; const float* gamma; const float* beta; float* xres_out;
+  const void* w; const float* bias;           // [3d][K] and [3d]
+  void* kc; void* vc; const int* kv_len; const int* active;
+  void* out;                                  // T [B][d]
+  int B, d, H, smax;
+};
+
+template <typename T, int HD, int KD>
+__global__ __launch_bounds__(256) void dec_qkv_attn_kernel(QkvAttnArgs a) {
+  typedef typename Frag16<T>::type F;
+  constexpr int G = DT<T>::G;
+  constexpr int KS = Frag16<T>::KS;
+  constexpr int RPG = 2;
+  constexpr int LPK = HD / G, KPI = 64 / LPK;
+  constexpr int EPL = KD / 64;                 // LayerNorm elements per lane
+  constexpr int LDXS = KD + G;
+  constexpr int NKS_ALL = KD / KS;             // k-steps of the projection
+  constexpr int NKS_W = NKS_ALL / 4;           // per wave
+  constexpr int KCH = NKS_W > 4 ? 4 : NKS_W;   // k-steps in flight per wave
+  static_assert(NKS_ALL % 4 == 0 && NKS_W % KCH == 0, "K split");
+  __shared__ __attribute__((aligned(16))) T xs[(RPG + 1) * LDXS];
+  __shared__ __attribute__((aligned(16))) float red[4 * 6 * 64 * 4];
+  __shared__ float qkv_s[RPG][3 * HD];
+  __shared__ float s_m[4];
+  __shared__ float s_acc[4][HD + 1];
+
+  const int h = blockIdx.x, rg = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = a.d, H = a.H, smax = a.smax;
+  const int part = lane % LPK, slot = lane / LPK;
+  const int arow = wave >> 1, half = wave & 1;          // attention: row of this wave, key-group parity
+  const int b_att = rg * RPG + arow;
+  const bool row_ok = b_att < a.B;
+  const int bsafe = row_ok ? b_att : 0;
+  const T* kb = (const T*)a.kc + ((long long)bsafe * H + h) * smax * HD;
+  const T* vb = (const T*)a.vc + ((long long)bsafe * H + h) * smax * HD;
+
+  // ---- (1) speculative K/V groups of this wave: group g = half + 2*i holds keys [g*KPI, (g+1)*KPI)
+  constexpr int SPEC = 4, NEXT = 6;
+  F ksp[SPEC], vsp[SPEC];
+#pragma unroll
+  for (int i = 0; i < SPEC; ++i) {
+    const int j = (half + 2 * i) * KPI + slot;
+    if (j < smax) { ksp[i] = *(const F*)(kb + (long long)j * HD + part * G); vsp[i] = *(const F*)(vb + (long long)j * HD + part * G); }
+    else {
+#pragma unroll
+      for (int e = 0; e < G; ++e) { ksp[i][e] = 0; vsp[i][e] = 0; }
+    }
+  }
+  const int act = row_ok ? a.active[bsafe] : 0;
+  const int nold = row_ok ? min(a.kv_len[bsafe], smax - 1) : 0;   // cached keys; the new key goes to position nold
+
+  // ---- (2) LayerNorm prologue: wave w < RPG normalises row w (fp32, two-pass), writes T copy to LDS
+  if (wave < RPG) {
+    const int b = rg * RPG + wave;
+    float v[EPL];
+    const bool live = b < a.B;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) v[i] = live ? a.yin[(long long)b * KD + lane + 64 * i] : 0.f;
+    if (a.gamma) {
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) sum += v[i];
+      const float mean = wave_sum(sum) / (float)KD;
+      float q2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) { float dl = v[i] - mean; q2 += dl * dl; }
+      const float rstd = rsqrtf(wave_sum(q2) / (float)KD + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) v[i] = live ? (v[i] - mean) * rstd * a.gamma[lane + 64 * i] + a.beta[lane + 64 * i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      xs[wave * LDXS + lane + 64 * i] = (T)v[i];
+      if (a.xres_out && h == 0 && live) a.xres_out[(long long)b * KD + lane + 64 * i] = v[i];
+    }
+  } else if (wave == RPG) {
+    for (int c = lane; c < LDXS; c += 64) xs[RPG * LDXS + c] = (T)0.f;     // zero row for the unused MFMA columns
+  }
+
+  // ---- (3) second K/V batch now that kv_len is known (same round trip as the speculative one)
+  F kn[NEXT], vn[NEXT];
+#pragma unroll
+  for (int i = 0; i < NEXT; ++i) {
+    const int j = (half + 2 * (SPEC + i)) * KPI + slot;
+    if (j < nold) { kn[i] = *(const F*)(kb + (long long)j * HD + part * G); vn[i] = *(const F*)(vb + (long long)j * HD + part * G); }
+    else {
+#pragma unroll
+      for (int e = 0; e < G; ++e) { kn[i][e] = 0; vn[i][e] = 0; }
+    }
+  }
+
+  // ---- (4) QKV projection of head h: 6 tiles of 16 weight rows (q|k|v x 2), K split over the 4 waves
+  f4v acc[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) acc[j] = (f4v){0.f, 0.f, 0.f, 0.f};
+  const int rowl = lane & 15, kg = lane >> 4;
+  const T* wbase = (const T*)a.w;
+  __syncthreads();                                                           // xs ready
+  for (int kc0 = 0; kc0 < NKS_W; kc0 += KCH) {
+    F af[KCH][6];
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int k = (wave * NKS_W + kc0 + i) * KS + G * kg;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int wrow = (j >> 1) * d + h * HD + (j & 1) * 16 + rowl;          // q rows, k rows, v rows of head h
+        af[i][j] = *(const F*)(wbase + (long long)wrow * KD + k);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int k = (wave * NKS_W + kc0 + i) * KS + G * kg;
+      const F bf = *(const F*)(xs + (rowl < RPG ? rowl : RPG) * LDXS + k);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) mma16(acc[j], af[i][j], bf);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) *(f4v*)(red + ((wave * 6 + j) * 64 + lane) * 4) = acc[j];
+  __syncthreads();
+  if (tid < RPG * 3 * HD) {
+    const int r = tid / (3 * HD), nl = tid - r * (3 * HD);     // nl: 0..31 q, 32..63 k, 64..95 v
+    const int j = nl >> 4, rr = nl & 15;
+    const int ln = (rr >> 2) * 16 + r, i = rr & 3;             // D layout: col = batch row, row = 4*(ln>>4)+i
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[((w * 6 + j) * 64 + ln) * 4 + i];
+    const int which = nl / HD, e = nl - which * HD;
+    v += a.bias[which * d + h * HD + e];
+    qkv_s[r][nl] = v;
+    const int b = rg * RPG + r;
+    if (which > 0 && b < a.B && a.active[b]) {                  // append the new key / value row in place
+      const int pos = min(a.kv_len[b], smax - 1);
+      T* base = (T*)(which == 1 ? a.kc : a.vc);
+      base[(((long long)b * H + h) * smax + pos) * HD + e] = (T)v;
+    }
+  }
+  __syncthreads();
+
+  // ---- (5) attention of (b_att, h): this wave's key groups + (half == 0) the new key from LDS
+  float qf[G];
+  {
+    const float scale = rsqrtf((float)HD);
+#pragma unroll
+    for (int i = 0; i < G; ++i) qf[i] = to_f((T)qkv_s[arow][part * G + i]) * scale;
+  }
+  float m = -INFINITY, l = 0.f, oacc[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) oacc[i] = 0.f;
+  auto consume = [&](const float* kf, const float* vf, bool ok) {
+    float sc = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) sc += qf[i] * kf[i];
+#pragma unroll
+    for (int o = 1; o < LPK; o <<= 1) sc += __shfl_xor(sc, o, 64);
+    if (ok) {
+      const float mn = fmaxf(m, sc);
+      const float corr = __expf(m - mn);
+      const float p = __expf(sc - mn);
+      l = l * corr + p;
+#pragma unroll
+      for (int i = 0; i < G; ++i) oacc[i] = oacc[i] * corr + p * vf[i];
+      m = mn;
+    }
+  };
+  auto consume_frag = [&](const F& kv, const F& vv, bool ok) {
+    float kf[G], vf[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) { kf[i] = to_f(kv[i]); vf[i] = to_f(vv[i]); }
+    consume(kf, vf, ok);
+  };
+  const bool live_row = row_ok && act;
+#pragma unroll
+  for (int i = 0; i < SPEC; ++i) consume_frag(ksp[i], vsp[i], live_row && (half + 2 * i) * KPI + slot < nold);
+#pragma unroll
+  for (int i = 0; i < NEXT; ++i) consume_frag(kn[i], vn[i], live_row && (half + 2 * (SPEC + i)) * KPI + slot < nold);
+  if (live_row) {
+    for (int j0 = (half + 2 * (SPEC + NEXT)) * KPI; j0 < nold; j0 += 2 * KPI) {
+      const int j = j0 + slot;
+      const bool ok = j < nold;
+      F kv, vv;
+      if (ok) { kv = *(const F*)(kb + (long long)j * HD + part * G); vv = *(const F*)(vb + (long long)j * HD + part * G); }
+      else {
+#pragma unroll
+        for (int e = 0; e < G; ++e) { kv[e] = 0; vv[e] = 0; }
+      }
+      consume_frag(kv, vv, ok);
+    }
+  }
+  {
+    // the key/value just produced (position nold), rounded to the cache dtype exactly as a later step reads it
+    float kf[G], vf[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) { kf[i] = to_f((T)qkv_s[arow][HD + part * G + i]); vf[i] = to_f((T)qkv_s[arow][2 * HD + part * G + i]); }
+    consume(kf, vf, live_row && half == 0 && slot == 0);
+  }
+  // combine the two waves of the row (and all key slots)
+  float wm = wave_max(m);
+  if (lane == 0) s_m[wave] = wm;
+  __syncthreads();
+  const float M = fmaxf(s_m[arow * 2], s_m[arow * 2 + 1]);
+  const float f = (m == -INFINITY) ? 0.f : __expf(m - M);
+  l *= f;
+#pragma unroll
+  for (int i = 0; i < G; ++i) oacc[i] *= f;
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    l += __shfl_xor(l, o, 64);
+#pragma unroll
+    for (int i = 0; i < G; ++i) oacc[i] += __shfl_xor(oacc[i], o, 64);
+  }
+  if (lane < LPK) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) s_acc[wave][lane * G + i] = oacc[i];
+    if (lane == 0) s_acc[wave][HD] = l;
+  }
+  __syncthreads();
+  if (tid < RPG * HD) {
+    const int r = tid / HD, e = tid - r * HD;
+    const int b = rg * RPG + r;
+    if (b < a.B && a.active[b]) {
+      const float L = s_acc[2 * r][HD] + s_acc[2 * r + 1][HD];
+      const float v = s_acc[2 * r][e] + s_acc[2 * r + 1][e];
+      ((T*)a.out)[(long long)b * d + h * HD + e] = (T)(v / L);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Sampling (H5): one wave per row, the whole row in registers (NPL values per lane), all
 // reductions are wavefront shuffles.  Semantics follow reference AR/models/utils.py:147-199:
 // repetition penalty (in place, so the EOS argmax test of t2s_model.py:721 sees penalised
@@ -627,8 +867,10 @@ __device__ void sample_row(const float* __restrict__ lg_row, int V, int Veff, co
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const int v = lane + 64 * i;
-    if (v >= Veff) continue;
-    float p = ((keep >> i) & 1u) ? expf(x[i] / tdiv - lm) / z : 0.f;
+    // filtered-out tokens have p = 0 and score 0 / q = 0: they can only win when no kept token has a
+    // positive score, which cannot happen (rank 0 is always kept), so their Exp(1) draw is never needed
+    if (v >= Veff || !((keep >> i) & 1u)) continue;
+    float p = expf(x[i] / tdiv - lm) / z;
     float qn;
     if (noise_row) qn = noise_row[v];
     else {
@@ -637,7 +879,7 @@ __device__ void sample_row(const float* __restrict__ lg_row, int V, int Veff, co
       qn = fmaxf(-log1pf(-u), 1e-20f);
     }
     float sc = p / qn;
-    if (sc > sv) { sv = sc; si = v; }
+    if (sc > sv || (sc == sv && v < si)) { sv = sc; si = v; }
   }
   ArgMax sm = wave_argmax(sv, si);
   *out_sample = sm.i;
@@ -792,7 +1034,7 @@ int launch_dec_gemm_inst(const DecGemmArgs& a, hipStream_t s) {
   if (KV4 > 0) lds += (size_t)CB * 16 * (a.K + G) * sizeof(T);
   auto kern = dec_gemm_kernel<T, CB, NW, KSL, KV4>;
   if (lds > 64 * 1024) GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(cdiv(a.N, 16)), dim3(NW * 64), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(cdiv(a.N, 16), cdiv(a.B, CB * 16)), dim3(NW * 64), lds, s, a);
   GSV_HIP(hipGetLastError());
   return GSV_OK;
 }
@@ -824,6 +1066,10 @@ int launch_dec_gemm_cb(const DecGemmArgs& a, bool lnpro, hipStream_t s) {
 
 template <typename T>
 int launch_dec_gemm(const DecGemmArgs& a, bool lnpro, hipStream_t s) {
+  // narrow outputs (N/16 < 64 workgroups, i.e. the N = 512 projections) are bound by what ONE CU can pull
+  // (its weight tile plus the whole X operand): give every 16-row batch block its own workgroup so twice
+  // as many CUs share the X traffic (the weight tile is then read once per block, from L2)
+  if (!lnpro && a.N / 16 < 64 && a.B > 16) return launch_dec_gemm_cb<T, 1>(a, lnpro, s);
   const int cb = cdiv(a.B, 16);
   if (cb <= 1) return launch_dec_gemm_cb<T, 1>(a, lnpro, s);
   if (cb <= 2) return launch_dec_gemm_cb<T, 2>(a, lnpro, s);
@@ -968,12 +1214,52 @@ static int launch_tail(gsv_t2s* h, hipStream_t s) {
   return GSV_OK;
 }
 
+template <typename T, int KD>
+static bool launch_qkv_attn_kd(const QkvAttnArgs& q, hipStream_t s) {
+  if constexpr ((KD / Frag16<T>::KS) % 4 == 0) {
+    hipLaunchKernelGGL((dec_qkv_attn_kernel<T, 32, KD>), dim3(q.H, cdiv(q.B, 2)), dim3(256), 0, s, q);
+    return true;
+  } else {
+    return false;   // contraction too short to split over 4 waves: the caller uses the unfused kernels
+  }
+}
+
+template <typename T>
+static bool launch_qkv_attn(const QkvAttnArgs& q, hipStream_t s) {
+  switch (q.d) {
+    case 64: return launch_qkv_attn_kd<T, 64>(q, s);
+    case 128: return launch_qkv_attn_kd<T, 128>(q, s);
+    case 256: return launch_qkv_attn_kd<T, 256>(q, s);
+    case 512: return launch_qkv_attn_kd<T, 512>(q, s);
+    case 1024: return launch_qkv_attn_kd<T, 1024>(q, s);
+    default: return false;
+  }
+}
+
 template <typename T>
 static int launch_decode_layers(gsv_t2s* h, hipStream_t s, int only_attn, hipEvent_t* attn_ev = nullptr) {
   const auto& c = h->cfg;
   const int d = c.dim, H = c.n_head;
   for (int li = 0; li < c.n_layer; ++li) {
     const LayerW& L = h->layers[li];
+    // The fused LN+QKV+append+attention kernel is OPT-IN: measured on MI355X at B=32 it is slower than the
+    // two separate launches (153.3 vs 148.1 ms per bench step): one workgroup per CU has to pull 96 KB of
+    // weights plus 72 KB of K/V through a single CU's memory path and runs LN -> MFMA -> reduce -> softmax
+    // as one serial chain, whereas the split kernels spread the same bytes over 96 + 512 workgroups.
+    static const bool use_fuse = getenv("GSV_FUSED_QKV_ATTN") != nullptr;
+    bool fused = false;
+    if (!only_attn && use_fuse) {
+      QkvAttnArgs q;
+      memset(&q, 0, sizeof(q));
+      q.yin = h->ybuf;
+      if (li > 0) { q.gamma = h->layers[li - 1].n2w; q.beta = h->layers[li - 1].n2b; }
+      q.xres_out = h->xres; q.w = L.qkv_w; q.bias = L.qkv_b;
+      q.kc = kv_ptr(h, li, 0); q.vc = kv_ptr(h, li, 1); q.kv_len = h->d_kv_len; q.active = h->d_active;
+      q.out = h->abuf; q.B = h->B; q.d = d; q.H = H; q.smax = h->max_seq;
+      fused = launch_qkv_attn<T>(q, s);
+    }
+    if (fused) {
+    } else {
     if (!only_attn) {
       DecGemmArgs a;
       memset(&a, 0, sizeof(a));
@@ -990,6 +1276,7 @@ static int launch_decode_layers(gsv_t2s* h, hipStream_t s, int only_attn, hipEve
                        (const T*)kv_ptr(h, li, 0), (const T*)kv_ptr(h, li, 1), h->d_kv_len, h->d_active, H, h->max_seq,
                        (T*)h->abuf);
     if (attn_ev) GSV_HIP(hipEventRecord(attn_ev[2 * li + 1], s));
+    }
     if (only_attn) continue;
     {
       DecGemmArgs a;

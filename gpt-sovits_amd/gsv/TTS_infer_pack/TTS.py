@@ -300,9 +300,11 @@ class TTS:
             if self.prompt_cache["phones"] is not None:
                 prompt_data = {"phones": self.prompt_cache["phones"], "bert_features": self.prompt_cache["bert_features"]}
             t1 = time.perf_counter()
+            # token ids stay on the host here: the engines pack a whole batch and move it with ONE copy
+            # (the reference's per-item .to(device), TTS.py:899-912, is ~75 tiny transfers per batch of 32)
             data, batch_index_list = self.to_batch(segments, prompt_data=prompt_data, batch_size=batch_size,
                                                    threshold=batch_threshold, split_bucket=split_bucket,
-                                                   device=self.configs.device, precision=self.precision)
+                                                   device=torch.device("cpu"), precision=self.precision)
             t2 = time.perf_counter()
             infer = (self.t2s_model.infer_panel_batch_infer if parallel_infer
                      else self.t2s_model.infer_panel_naive_batched)

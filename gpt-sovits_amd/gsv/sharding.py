@@ -55,8 +55,8 @@ def unpack_segments(buf: torch.Tensor) -> List[dict]:
 
 
 class ShardedSynthesizer:
-    """`synth(segments) -> (int16 1-D tensor on `device`, per-fragment sample counts in the order of
-    `segments`)` is the local engine call (TTS wrapper in production, a stub in the gloo tests)."""
+    """`synth(segments) -> (int16 1-D numpy array or device tensor, per-fragment sample counts in the
+    order of `segments`)` is the local engine call (TTS wrapper in production, a stub in the gloo tests)."""
 
     def __init__(self, synth: Callable[[List[dict]], Tuple[torch.Tensor, List[int]]], device: torch.device,
                  group=None):
@@ -84,10 +84,14 @@ class ShardedSynthesizer:
             segments = unpack_segments(wire)
         shares = deal_contiguous([len(s["norm_text"]) for s in segments], self.world)
         mine = shares[self.rank]
-        audio, frag_lens = self.synth([segments[i] for i in mine]) if mine else (torch.zeros(0, dtype=torch.int16, device=dev), [])
-        assert audio.dtype == torch.int16 and sum(frag_lens) == audio.numel()
+        audio, frag_lens = self.synth([segments[i] for i in mine]) if mine else (np.zeros(0, dtype=np.int16), [])
         if self.world == 1:
-            return _reorder([audio.cpu().numpy()], [frag_lens], shares, len(segments))
+            a = audio.cpu().numpy() if torch.is_tensor(audio) else audio
+            assert a.dtype == np.int16 and sum(frag_lens) == a.size
+            return _reorder([a], [frag_lens], shares, len(segments))
+        if not torch.is_tensor(audio):
+            audio = torch.from_numpy(audio).to(dev)     # the gather works on device buffers (RCCL)
+        assert audio.dtype == torch.int16 and sum(frag_lens) == audio.numel()
         # ---- gather (lengths, then one padded gather to rank 0)
         n_local = torch.tensor([audio.numel()], dtype=torch.int64, device=dev)
         all_n = [torch.zeros_like(n_local) for _ in range(self.world)]
