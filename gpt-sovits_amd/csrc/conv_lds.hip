@@ -299,6 +299,197 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Plain GEMM (taps == 1): Y[t][n] = X[t][:] . W[n][:], the prefill projections (M = sum of prompt
+// lengths, K = 512 / 2048) and the 1x1 convs of enc_p.  128 (n) x 128 (t) tile, BK = 64, both
+// operands double-buffered in LDS through registers: the loads of K-chunk c+1 are in flight while
+// chunk c feeds 16 MFMAs per wave, one barrier per chunk; ~74 KB of LDS -> two workgroups per CU.
+// ---------------------------------------------------------------------------------------
+template <typename T, bool RES>
+__global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
+  typedef typename FragL<T>::type F;
+  constexpr int G = DT<T>::G, KC = 2 * G;
+  constexpr int BK = 64 * 2 / (int)sizeof(T);        // 64 fp16 / 32 fp32 elements = 128 B per row
+  constexpr int LDX = BK + G;
+  constexpr int VPR = BK / G;                        // 8 vectors per row
+  constexpr int CT = 128, TT = 128, NT = 256;
+  constexpr int NLD = CT * VPR / NT;                 // vectors per thread per operand per chunk (4)
+  constexpr int TM = 2, TN = 2, WN = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* xs = (T*)smem;                                  // [2][TT][LDX]
+  T* ws = xs + 2 * TT * LDX;                         // [2][CT][LDX]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int t0 = blockIdx.x * TT, cout0 = blockIdx.y * CT;
+  const T* __restrict__ x = (const T*)a.x;
+  const T* __restrict__ w = (const T*)a.w;
+  const int K = a.Cin;
+
+  // epilogue operands first (see conv_lds_kernel)
+  constexpr int LDO = CT + 4, PR = TN * 32, IPR = CT / 4, NI = PR * IPR / NT;
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  const bool vec_ok = ((a.ldy & 3) == 0) && ((a.y_col0 & 3) == 0) && ((a.ldr & 3) == 0);
+  const int ecg = tid % IPR, ec = cout0 + 4 * ecg;
+  const int env = max(0, min(4, a.Cout - ec));
+  f4 ebias = (f4){0.f, 0.f, 0.f, 0.f};
+  if (a.bias) for (int j = 0; j < env; ++j) ebias[j] = a.bias[ec + j];
+  T4 rv[RES ? WN * NI : 1];
+  rv[0] = (T4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+  if (RES) {
+#pragma unroll
+    for (int q = 0; q < WN * NI; ++q) {
+      rv[q] = (T4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+      const int pass = q / NI, e = q - pass * NI;
+      const int t = t0 + pass * PR + (tid + e * NT) / IPR;
+      if (t < a.T_virt && env > 0) {
+        const T* rp = (const T*)a.res + (long long)t * a.ldr + ec;
+        if (vec_ok && env == 4) rv[q] = *(const T4*)rp;
+        else for (int j = 0; j < env; ++j) rv[q][j] = rp[j];
+      }
+    }
+  }
+
+  f16v acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  auto load_tiles = [&](int k0, F* xr, F* wr) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int v = tid + i * NT;
+      const int row = v / VPR, col = v - row * VPR;
+      const int kk = k0 + col * G;
+      const int t = t0 + row, co = cout0 + row;
+      xr[i] = (t < a.T_in && kk < K) ? *(const F*)(x + (long long)t * a.ldx + kk) : zfrag<F>();
+      wr[i] = (co < a.Cout && kk < K) ? *(const F*)(w + (long long)co * a.ldw + kk) : zfrag<F>();
+    }
+  };
+  auto store_tiles = [&](int buf, F* xr, const F* wr) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int v = tid + i * NT;
+      const int row = v / VPR, col = v - row * VPR;
+      F val = xr[i];
+      if (a.pre_act == ACT_LRELU) val = lrelu_l(val, a.pre_slope);
+      else if (a.pre_act == ACT_RELU) val = relu_l(val);
+      *(F*)(xs + ((size_t)buf * TT + row) * LDX + col * G) = val;
+      *(F*)(ws + ((size_t)buf * CT + row) * LDX + col * G) = wr[i];
+    }
+  };
+  {
+    F xr[NLD], wr[NLD];
+    load_tiles(0, xr, wr);
+    store_tiles(0, xr, wr);
+  }
+  __syncthreads();
+  const int nchunks = (K + BK - 1) / BK;
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    F xr[NLD], wr[NLD];
+    const bool more = c + 1 < nchunks;
+    if (more) load_tiles((c + 1) * BK, xr, wr);
+    const T* xb = xs + (size_t)buf * TT * LDX;
+    const T* wb = ws + (size_t)buf * CT * LDX;
+#pragma unroll
+    for (int ks = 0; ks < BK / KC; ++ks) {
+      const int kk = ks * KC + G * h;
+      F af[TM], bf[TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m) af[m] = *(const F*)(wb + (size_t)((wm * TM + m) * 32 + r) * LDX + kk);
+#pragma unroll
+      for (int n = 0; n < TN; ++n) bf[n] = *(const F*)(xb + (size_t)((wn * TN + n) * 32 + r) * LDX + kk);
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) mma32l(acc[m][n], af[m], bf[n]);
+    }
+    if (more) {
+      store_tiles(buf ^ 1, xr, wr);
+      __syncthreads();
+    }
+  }
+
+  float* os = (float*)smem;                           // [PR][LDO]
+#pragma unroll
+  for (int pass = 0; pass < WN; ++pass) {
+    __syncthreads();
+    if (wn == pass) {
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+          const int tl = n * 32 + r;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cl = (wm * TM + m) * 32 + 8 * g + 4 * h;
+            *(f4*)(os + (size_t)tl * LDO + cl) = (f4){acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+          }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+      const int q = pass * NI + e;
+      const int tl = (tid + e * NT) / IPR;
+      const int t = t0 + pass * PR + tl;
+      if (!(t < a.T_virt && env > 0)) continue;
+      const f4 av = *(const f4*)(os + (size_t)tl * LDO + 4 * ecg);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float u = av[j] + ebias[j];
+        if (RES) u += to_f(rv[q][j]);
+        u *= a.scale;
+        if (a.post_act == ACT_RELU) u = fmaxf(u, 0.f);
+        else if (a.post_act == ACT_TANH) u = tanhf(u);
+        else if (a.post_act == ACT_MISH) u = u * tanhf(u > 20.f ? u : log1pf(expf(u)));
+        else if (a.post_act == ACT_CLAMP1) u = fminf(fmaxf(u, -1.f), 1.f);
+        v[j] = u;
+      }
+      const long long yoff = (long long)t * a.ldy + a.y_col0 + ec;
+      const bool vec = vec_ok && env == 4;
+      if (a.out_f32) {
+        float* yp = (float*)a.y + yoff;
+        if (vec) *(f4*)yp = (f4){v[0], v[1], v[2], v[3]};
+        else for (int j = 0; j < env; ++j) yp[j] = v[j];
+      } else {
+        T* yp = (T*)a.y + yoff;
+        if (vec) *(T4*)yp = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+        else for (int j = 0; j < env; ++j) yp[j] = (T)v[j];
+      }
+    }
+  }
+}
+
+template <typename T> static int try_launch_gemm(const ConvArgs& a, hipStream_t s) {
+  constexpr int G = DT<T>::G;
+  constexpr int BK = 64 * 2 / (int)sizeof(T);
+  if (a.Z != 1 || a.taps != 1 || a.stride != 1 || a.ups_u > 0 || a.accumulate || a.pad != 0) return 1;
+  if (a.T_virt < 512 || a.Cout < 96 || a.Cin % (2 * G) != 0 || a.Cin < BK) return 1;
+  if (a.res && a.res_f32) return 1;
+  if (a.ldx % G != 0 || a.ldw % G != 0 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return 1;
+  const size_t lds = (size_t)2 * (128 + 128) * (BK + G) * sizeof(T);     // 73.7 KB; epilogue tile 33.8 KB fits inside
+  dim3 grid(cdiv(a.T_virt, 128), cdiv(a.Cout, 128), 1);
+  if (a.res) {
+    auto kern = gemm_lds_kernel<T, true>;
+    static bool set = false;
+    if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  } else {
+    auto kern = gemm_lds_kernel<T, false>;
+    static bool set = false;
+    if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  }
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
 template <typename T, int TM, int TN, int WM, int WN, int CC, bool ALLW, bool RES, bool ACCU>
 static int launch_inst2(const ConvArgs& a, int rows_win, int lo, hipStream_t s) {
   constexpr int G = DT<T>::G;
@@ -363,6 +554,10 @@ template <typename T> static int try_launch(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_conv_lds(int dtype, const ConvArgs& a, hipStream_t s) {
+  int rc = 1;
+  if (dtype == GSV_F16) rc = try_launch_gemm<_Float16>(a, s);
+  else if (dtype == GSV_F32) rc = try_launch_gemm<float>(a, s);
+  if (rc != 1) return rc;
   if (dtype == GSV_F16) return try_launch<_Float16>(a, s);
   if (dtype == GSV_F32) return try_launch<float>(a, s);
   return 1;

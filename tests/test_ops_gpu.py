@@ -126,7 +126,8 @@ def test_layernorm_matches_torch():
 @pytest.mark.parametrize("Cin,Cout,k,dil,T", [(256, 256, 11, 5, 700), (192, 512, 7, 1, 300), (128, 128, 3, 3, 1111),
                                                (64, 64, 7, 5, 2000), (32, 32, 11, 1, 1500), (16, 16, 3, 5, 4100),
                                                (16, 1, 7, 1, 3000), (768, 192, 3, 1, 260), (192, 384, 5, 1, 513),
-                                               (96, 192, 1, 1, 400)])
+                                               (96, 192, 1, 1, 400), (512, 1536, 1, 1, 700), (2048, 512, 1, 1, 600),
+                                               (192, 576, 1, 1, 1000), (704, 128, 1, 1, 520)])
 def test_conv1d_lds_path_matches_torch(dtype, tol, Cin, Cout, k, dil, T):
     """T >= 256 and stride 1 route through the LDS-staged kernel (conv_lds.hip): every tile config,
     partial channel chunks (192 = 128 + 64), halo rows outside the sequence, Cout = 1 (conv_post)."""
