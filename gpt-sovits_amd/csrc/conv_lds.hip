@@ -322,8 +322,10 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int t0 = blockIdx.x * TT, cout0 = blockIdx.y * CT;
-  const T* __restrict__ x = (const T*)a.x;
-  const T* __restrict__ w = (const T*)a.w;
+  const int z = blockIdx.z;                            // batch (attention heads): operand / output offsets
+  const T* __restrict__ x = (const T*)a.x + (long long)z * a.xz;
+  const T* __restrict__ w = (const T*)a.w + (long long)z * a.wz;
+  const long long ybase = (long long)z * a.yz, rbase = (long long)z * a.rz;
   const int K = a.Cin;
 
   // epilogue operands first (see conv_lds_kernel)
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
       const int pass = q / NI, e = q - pass * NI;
       const int t = t0 + pass * PR + (tid + e * NT) / IPR;
       if (t < a.T_virt && env > 0) {
-        const T* rp = (const T*)a.res + (long long)t * a.ldr + ec;
+        const T* rp = (const T*)a.res + rbase + (long long)t * a.ldr + ec;
         if (vec_ok && env == 4) rv[q] = *(const T4*)rp;
         else for (int j = 0; j < env; ++j) rv[q][j] = rp[j];
       }
@@ -451,8 +453,8 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
         else if (a.post_act == ACT_CLAMP1) u = fminf(fmaxf(u, -1.f), 1.f);
         v[j] = u;
       }
-      const long long yoff = (long long)t * a.ldy + a.y_col0 + ec;
-      const bool vec = vec_ok && env == 4;
+      const long long yoff = ybase + (long long)t * a.ldy + a.y_col0 + ec;
+      const bool vec = vec_ok && env == 4 && ((ybase & 3) == 0);
       if (a.out_f32) {
         float* yp = (float*)a.y + yoff;
         if (vec) *(f4*)yp = (f4){v[0], v[1], v[2], v[3]};
@@ -469,12 +471,13 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
 template <typename T> static int try_launch_gemm(const ConvArgs& a, hipStream_t s) {
   constexpr int G = DT<T>::G;
   constexpr int BK = 64 * 2 / (int)sizeof(T);
-  if (a.Z != 1 || a.taps != 1 || a.stride != 1 || a.ups_u > 0 || a.accumulate || a.pad != 0) return 1;
+  if (a.taps != 1 || a.stride != 1 || a.ups_u > 0 || a.accumulate || a.pad != 0) return 1;
   if (a.T_virt < 512 || a.Cout < 96 || a.Cin % (2 * G) != 0 || a.Cin < BK) return 1;
+  if (a.Z > 1 && ((a.xz % G) || (a.wz % G) || a.res)) return 1;      // batched: head slices must stay 16-byte aligned
   if (a.res && a.res_f32) return 1;
   if (a.ldx % G != 0 || a.ldw % G != 0 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return 1;
   const size_t lds = (size_t)2 * (128 + 128) * (BK + G) * sizeof(T);     // 73.7 KB; epilogue tile 33.8 KB fits inside
-  dim3 grid(cdiv(a.T_virt, 128), cdiv(a.Cout, 128), 1);
+  dim3 grid(cdiv(a.T_virt, 128), cdiv(a.Cout, 128), a.Z);
   if (a.res) {
     auto kern = gemm_lds_kernel<T, true>;
     static bool set = false;

@@ -125,6 +125,10 @@ int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream) {
     a.ldy = d->Cout; a.ldr = d->Cout;
     a.T_virt = d->T_out;
   }
+  if (d->ldx > 0) a.ldx = d->ldx;
+  if (d->ldw > 0) a.ldw = d->ldw;
+  if (d->ldy > 0) { a.ldy = d->ldy; a.ldr = d->ldy; }
+  if (d->Z > 1) { a.Z = d->Z; a.xz = d->xz; a.wz = d->wz; a.yz = d->yz; }
   return gsv::launch_conv_gemm(dtype, a, (hipStream_t)stream);
 }
 }

@@ -160,10 +160,14 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     }
     __syncthreads();
   }
+  // the biased row is kept in LDS (<= 12288 keys) so the fp32 scores are read from HBM once, not three times
+  extern __shared__ float s_row[];
+  const bool cached = Tk <= 12288;
   float m = -INFINITY;
   for (int j = tid; j < Tk; j += 256) {
     float v = srow[j];
     if (w > 0) { int r = j - i + w; if (r >= 0 && r <= 2 * w) v += s_bias[r]; }
+    if (cached) s_row[j] = v;
     m = fmaxf(m, v);
   }
   m = wave_max(m);
@@ -172,9 +176,15 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
   float sum = 0.f;
   for (int j = tid; j < Tk; j += 256) {
-    float v = srow[j];
-    if (w > 0) { int r = j - i + w; if (r >= 0 && r <= 2 * w) v += s_bias[r]; }
-    sum += expf(v - m);
+    float v;
+    if (cached) v = s_row[j];
+    else {
+      v = srow[j];
+      if (w > 0) { int r = j - i + w; if (r >= 0 && r <= 2 * w) v += s_bias[r]; }
+    }
+    const float e = expf(v - m);
+    if (cached) s_row[j] = e;
+    sum += e;
   }
   sum = wave_sum(sum);
   if (lane == 0) s_red[4 + wave] = sum;
@@ -184,11 +194,14 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   for (int j = tid; j < ldp; j += 256) {
     float p = 0.f;
     if (j < Tk) {
-      float v = srow[j];
       int r = j - i + w;
       const bool inband = w > 0 && r >= 0 && r <= 2 * w;
-      if (inband) v += s_bias[r];
-      p = expf(v - m) * inv;
+      if (cached) p = s_row[j] * inv;
+      else {
+        float v = srow[j];
+        if (inband) v += s_bias[r];
+        p = expf(v - m) * inv;
+      }
       if (inband) band[((long long)z * Tq + i) * (2 * w + 1) + r] = p;
     }
     prow[j] = (T)p;
@@ -575,9 +588,9 @@ int attention(gsv_vits* h, hipStream_t s, const void* q, int ldq, int qcol0, con
   GSV_RC(launch_conv_gemm(h->dtype, a, s));
   const int w = rel_k ? 4 : 0;
   GSV_DISPATCH(h,
-    hipLaunchKernelGGL(softmax_rows_kernel<_Float16>, dim3(Tq, nh), dim3(256), 0, s, (const float*)scores, Tq, Tk, ldp, (_Float16*)P,
+    hipLaunchKernelGGL(softmax_rows_kernel<_Float16>, dim3(Tq, nh), dim3(256), Tk <= 12288 ? (size_t)Tk * 4 : 0, s, (const float*)scores, Tq, Tk, ldp, (_Float16*)P,
                        (const _Float16*)q + qcol0, ldq, kc, rel_k, w, scale, (float*)band),
-    hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(Tq, nh), dim3(256), 0, s, (const float*)scores, Tq, Tk, ldp, (float*)P,
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(Tq, nh), dim3(256), Tk <= 12288 ? (size_t)Tk * 4 : 0, s, (const float*)scores, Tq, Tk, ldp, (float*)P,
                        (const float*)q + qcol0, ldq, kc, rel_k, w, scale, (float*)band));
   GSV_DISPATCH(h,
     hipLaunchKernelGGL(transpose_v_kernel<_Float16>, dim3(cdiv(ldp, 32), cdiv(kc, 32), nh), dim3(256), 0, s, (const _Float16*)kv, ldkv,

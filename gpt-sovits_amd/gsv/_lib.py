@@ -41,7 +41,9 @@ class ConvDesc(C.Structure):
                 ("T_in", C.c_int), ("T_out", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("taps", C.c_int),
                 ("stride", C.c_int), ("dil", C.c_int), ("pad", C.c_int), ("pre_act", C.c_int),
                 ("pre_slope", C.c_float), ("post_act", C.c_int), ("scale", C.c_float), ("accumulate", C.c_int),
-                ("out_f32", C.c_int), ("ups_u", C.c_int), ("ups_pad", C.c_int)]
+                ("out_f32", C.c_int), ("ups_u", C.c_int), ("ups_pad", C.c_int),
+                ("Z", C.c_int), ("xz", C.c_longlong), ("wz", C.c_longlong), ("yz", C.c_longlong),
+                ("ldx", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int)]
 
 
 _SIGS = {

@@ -186,6 +186,8 @@ typedef struct {
   int T_in, T_out, Cin, Cout, taps, stride, dil, pad;
   int pre_act; float pre_slope; int post_act; float scale; int accumulate; int out_f32;
   int ups_u, ups_pad;
+  /* optional (0 = defaults): batched GEMM over Z slices with element strides, explicit leading dims */
+  int Z; long long xz, wz, yz; int ldx, ldw, ldy;
 } gsv_conv_desc;
 /* channels-last conv1d: x [T_in][Cin], w [Cout][taps*Cin] (tap-major, cin fastest), y [T_out][Cout] */
 int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream);

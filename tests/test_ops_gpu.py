@@ -175,3 +175,39 @@ def test_transposed_conv_lds_path(u, k, Cin, Cout, T):
     _lib.check(_lib.lib().gsv_op_conv1d(C.byref(d), _lib.dtype_code(dtype), None))
     torch.cuda.synchronize()
     assert (y.float().cpu().t() - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.float16, 2e-2)])
+@pytest.mark.parametrize("Tq,Tk,nh,kc", [(700, 650, 2, 96), (1300, 520, 4, 128)])
+def test_batched_attention_gemms(dtype, tol, Tq, Tk, nh, kc):
+    """the two attention products of enc_p as batched GEMMs over heads (Z = heads, strided head slices):
+    scores = scale * Q K^T (fp32 out) and out = P V^T-layout, both through the LDS GEMM kernel."""
+    from gsv import _lib
+    _lib.init(0)
+    torch.manual_seed(Tq + Tk)
+    H = nh * kc
+    q = torch.randn(Tq, H)
+    k = torch.randn(Tk, H)
+    qd, kd = q.to(DEV, dtype).contiguous(), k.to(DEV, dtype).contiguous()
+    sc = torch.zeros(nh, Tq, Tk, device=DEV)
+    d = _lib.ConvDesc(qd.data_ptr(), kd.data_ptr(), None, sc.data_ptr(), None, Tq, Tq, kc, Tk, 1, 1, 1, 0, 0, 0.0, 0, 0.125, 0,
+                      1, 0, 0, nh, kc, kc, Tq * Tk, H, H, Tk)
+    _lib.check(_lib.lib().gsv_op_conv1d(C.byref(d), _lib.dtype_code(dtype), None))
+    torch.cuda.synchronize()
+    ref = torch.einsum("qhc,khc->hqk", q.view(Tq, nh, kc), k.view(Tk, nh, kc)) * 0.125
+    assert (sc.cpu() - ref).abs().max().item() < tol * ref.abs().max().item()
+    # P [nh][Tq][Tkp] x Vt [nh][kc][Tkp] -> out [Tq][H]
+    Tkp = (Tk + 7) // 8 * 8
+    P = torch.zeros(nh, Tq, Tkp)
+    P[:, :, :Tk] = torch.softmax(ref, dim=-1)
+    v = torch.randn(Tk, H)
+    Vt = torch.zeros(nh, kc, Tkp)
+    Vt[:, :, :Tk] = v.view(Tk, nh, kc).permute(1, 2, 0)
+    Pd, Vd = P.to(DEV, dtype).contiguous(), Vt.to(DEV, dtype).contiguous()
+    out = torch.zeros(Tq, H, device=DEV, dtype=dtype)
+    d2 = _lib.ConvDesc(Pd.data_ptr(), Vd.data_ptr(), None, out.data_ptr(), None, Tq, Tq, Tkp, kc, 1, 1, 1, 0, 0, 0.0, 0, 1.0, 0,
+                       0, 0, 0, nh, Tq * Tkp, kc * Tkp, kc, Tkp, Tkp, H)
+    _lib.check(_lib.lib().gsv_op_conv1d(C.byref(d2), _lib.dtype_code(dtype), None))
+    torch.cuda.synchronize()
+    ref2 = torch.einsum("hqk,khc->qhc", P[:, :, :Tk], v.view(Tk, nh, kc)).reshape(Tq, H)
+    assert (out.float().cpu() - ref2).abs().max().item() < tol * max(1.0, ref2.abs().max().item())
