@@ -1,0 +1,124 @@
+"""GPU: the whole v2 path through TTS.run (to_batch -> AR -> time-folded SoVITS decode -> post-process)
+against the same chain built from the oracles, on reduced models in fp32."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases
+from oracle.t2s_oracle import T2SOracle
+from oracle.vits_oracle import VitsOracle
+from gsv import synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(is_half=False, max_sec=0.4):
+    from gsv.TTS_infer_pack.TTS import TTS
+    tcfg = S.small_t2s_config(n_layer=2, dim=128, head=4, vocab=1025, phoneme_vocab=732)
+    tcfg["data"]["max_sec"] = max_sec                       # early_stop_num = 50 * max_sec = 20 tokens
+    tsd = S.make_t2s_state_dict(tcfg, seed=11, suppress_eos=True)
+    vcfg = S.small_vits_config()
+    vsd = S.make_vits_state_dict(vcfg, seed=12)
+    tts = TTS({"device": DEV, "is_half": is_half, "version": "v2", "max_batch": 4, "max_seq": 256})
+    tts.init_t2s_weights(state={"weight": tsd, "config": tcfg})
+    tts.init_vits_weights(state={"weight": vsd, "config": vcfg})
+    return tts, tcfg, tsd, vcfg, vsd
+
+
+def test_tts_run_matches_oracle_chain():
+    tts, tcfg, tsd, vcfg, vsd = _build()
+    utt = S.make_utterances(5, prompt_phones=6, target_phones=9, prompt_tokens=8, seed=21, ragged=True)
+    for i, it in enumerate(utt["items"]):                  # distinct text lengths -> bucketing reorders
+        it["norm_text"] = "x" * [7, 3, 9, 4, 8][i]
+    refer = S.make_refer_spec(frames=30, seed=5)
+    segs = [{"phones": it["phones"], "bert_features": torch.zeros(1024, len(it["phones"])), "norm_text": it["norm_text"]}
+            for it in utt["items"]]
+    tts.set_prompt_cache(utt["prompt_semantic"], [refer.to(DEV)], phones=utt["prompt_phones"],
+                         bert_features=torch.zeros(1024, 6), norm_text="xxxxxx")
+    # inject the SoVITS noise (TTS.run itself uses the counter RNG): one draw per decode call
+    real_decode = tts.vits_model.decode
+    IC = vcfg["model"]["inter_channels"]
+    noises = []
+
+    def decode_with_noise(codes, text, refer_, **kw):
+        nz = S.hash_normal(f"pipe_noise{len(noises)}", (IC, 2 * codes.shape[-1]), 0)
+        noises.append(nz)
+        kw.pop("seed", None)
+        return real_decode(codes, text, refer_, noise=nz, **kw)
+
+    tts.vits_model.decode = decode_with_noise
+    out = list(tts.run({"segments": segs, "batch_size": 2, "top_k": 1, "top_p": 1.0, "temperature": 1.0,
+                        "repetition_penalty": 1.35, "seed": 3, "split_bucket": True, "fragment_interval": 0.01}))
+    assert len(out) == 1
+    sr, audio = out[0]
+    assert sr == 32000 and audio.dtype == np.int16
+
+    # ---- the same chain from the oracles
+    t2s, vits = T2SOracle(tsd, tcfg), VitsOracle(vsd, vcfg)
+    data, index = tts.to_batch(segs, {"phones": utt["prompt_phones"], "bert_features": torch.zeros(1024, 6)},
+                               batch_size=2, threshold=0.75, split_bucket=True)
+    up = math.prod(vcfg["model"]["upsample_rates"])
+    frags_by_batch = []
+    for bi, item in enumerate(data):
+        n = len(item["all_phones"])
+        berts = [torch.zeros(1024, int(t.shape[0])) for t in item["all_phones"]]
+        ys, idxs = t2s.infer_panel_batch_infer(item["all_phones"], None, utt["prompt_semantic"].view(1, -1).expand(n, -1),
+                                               berts, top_k=1, top_p=1.0, temperature=1.0, early_stop_num=20,
+                                               repetition_penalty=1.35)
+        pred = [y[-i:] for y, i in zip(ys, idxs)]
+        wav = vits.decode(torch.cat(pred).view(1, 1, -1), torch.cat(item["phones"]).view(1, -1), [refer], noise=noises[bi])[0, 0]
+        fr, o = [], 0
+        for p in pred:
+            fr.append(wav[o:o + p.shape[0] * 2 * up])
+            o += p.shape[0] * 2 * up
+        frags_by_batch.append(fr)
+    zero = torch.zeros(int(32000 * 0.01))
+    post = [[torch.cat([f / max(1.0, float(f.abs().max())), zero]) for f in fr] for fr in frags_by_batch]
+    flat = tts.recovery_order(post, index)
+    ref = (torch.cat(flat).numpy() * 32768).astype(np.int16)
+    assert audio.shape == ref.shape
+    assert np.abs(audio.astype(np.int32) - ref.astype(np.int32)).max() <= 4      # fp32 engine: waveform <= 1e-4 -> <= 4 LSB
+    assert tts.last_generated_tokens == 5 * 20
+
+
+def test_tts_run_error_protocol_and_stop_on_gpu():
+    tts, *_ = _build()
+    # no prompt cache -> NO_PROMPT_ERROR after one second of silence (reference TTS.py:1078, 1352-1363)
+    from gsv.TTS_infer_pack.TTS import NO_PROMPT_ERROR
+    gen = tts.run({"segments": [{"phones": [1, 2, 3], "bert_features": None, "norm_text": "abc"}]})
+    sr, a = next(gen)
+    assert sr == 16000 and a.shape == (16000,) and not a.any()
+    with pytest.raises(NO_PROMPT_ERROR):
+        next(gen)
+    # engines were rebuilt by the error protocol and still work; empty segment list -> 1 s of silence
+    assert tts.t2s_model is not None and tts.vits_model is not None
+    sr, a = next(tts.run({"segments": []}))
+    assert sr == 16000 and not a.any()
+
+
+def test_get_tts_wav_cli_path_matches_oracle_tokens_and_scaling():
+    """inference_cli / get_tts_wav glue (naive AR entry point, per-sentence decode, x32767)."""
+    from gsv.inference_cli import get_tts_wav
+    tts, tcfg, tsd, vcfg, vsd = _build(max_sec=0.3)
+    utt = S.make_utterances(2, prompt_phones=5, target_phones=8, prompt_tokens=7, seed=31)
+    refer = S.make_refer_spec(frames=25, seed=6)
+    prompt_seg = {"phones": utt["prompt_phones"], "bert_features": None}
+    segs = [{"phones": it["phones"], "bert_features": None, "norm_text": it["norm_text"]} for it in utt["items"]]
+    res = list(get_tts_wav(tts.t2s_model, tts.vits_model, utt["prompt_semantic"], refer.to(DEV), prompt_seg, segs,
+                           top_k=1, max_sec=0.3, hz=50))
+    assert len(res) == 1
+    sr, audio = res[0]
+    # token count: naive loop masks EOS for 11 steps; early stop at 15 tokens per sentence
+    t2s = T2SOracle(tsd, tcfg)
+    n_tok = 0
+    for it in utt["items"]:
+        ids = torch.LongTensor(utt["prompt_phones"] + it["phones"]).unsqueeze(0)
+        y, idx = t2s.infer_panel_naive(ids, None, utt["prompt_semantic"].view(1, -1), torch.zeros(1, 1024, ids.shape[1]),
+                                       top_k=1, top_p=1.0, temperature=1.0, early_stop_num=15)
+        n_tok += idx
+    up = math.prod(vcfg["model"]["upsample_rates"])
+    assert audio.shape[0] == n_tok * 2 * up + 2 * int(32000 * 0.3)
+    assert sr == 32000 and audio.dtype == np.int16 and np.abs(audio).max() <= 32767
