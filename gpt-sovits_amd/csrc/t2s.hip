@@ -13,6 +13,7 @@
 // combine (no global partials), then logits + a one-wave-per-row sampling kernel.
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
   const int K = a.K;
   const int ldx = K + G;  // padded LDS row (elements): breaks the power-of-two row stride
   T* xs = (T*)smem;
-  float* red = (float*)(smem + (LNPRO ? (size_t)CB * 16 * ldx * sizeof(T) : 0));
+  float* red = (float*)smem;   // the split-K combine buffer reuses the X image (barrier below)
 
   const int rowl = lane & 15, kg = lane >> 4;
   const int kbeg = wave * KSL;
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) mma16(acc[cb], af[i], bf[i][cb]);
   // combine the NW partial tiles through LDS (fixed summation order: deterministic)
+  if (LNPRO) __syncthreads();   // every wave has its B fragments in registers: the X image may be overwritten
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) *(f4v*)(red + ((wave * CB + cb) * 64 + lane) * 4) = acc[cb];
   __syncthreads();
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   for (int i = 0; i < SPEC; ++i) consume(ksp[i], vsp[i], (wave + 4 * i) * KPI + slot < n);
 #pragma unroll
   for (int i = 0; i < NEXT; ++i) consume(kn[i], vn[i], (wave + 4 * (SPEC + i)) * KPI + slot < n);
-#pragma unroll 4
+#pragma unroll 8
   for (int j0 = (wave + 4 * (SPEC + NEXT)) * KPI; j0 < n; j0 += 4 * KPI) {
     const int j = j0 + slot;
     const bool ok = j < n;
@@ -1031,7 +1033,7 @@ template <typename T, int CB, int NW, int KSL, int KV4>
 int launch_dec_gemm_inst(const DecGemmArgs& a, hipStream_t s) {
   constexpr int G = DT<T>::G;
   size_t lds = (size_t)NW * CB * 64 * 16;
-  if (KV4 > 0) lds += (size_t)CB * 16 * (a.K + G) * sizeof(T);
+  if (KV4 > 0) lds = std::max(lds, (size_t)CB * 16 * (a.K + G) * sizeof(T));
   auto kern = dec_gemm_kernel<T, CB, NW, KSL, KV4>;
   if (lds > 64 * 1024) GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(cdiv(a.N, 16), cdiv(a.B, CB * 16)), dim3(NW * 64), lds, s, a);
@@ -1541,6 +1543,20 @@ int gsv_t2s_time_step(gsv_t2s_t* h, int iters, float* step_ms, float* attn_ms, g
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
+}
+
+int gsv_t2s_debug_set_state(gsv_t2s_t* h, int B, int kv_len) {
+  // measurement hook: pretend B rows hold kv_len cached positions each (cache contents are whatever the
+  // arena holds); used by tools/attn_sweep.py to time the decode-attention kernel at other (B, S) points
+  GSV_REQUIRE(h && h->finalized, "t2s_debug_set_state: handle not finalized");
+  GSV_REQUIRE(B >= 1 && B <= h->max_batch && kv_len >= 1 && kv_len + 2 <= h->max_seq, "t2s_debug_set_state: out of range");
+  std::vector<int> kv(B, kv_len), zero(B, 0);
+  GSV_HIP(hipMemcpy(h->d_kv_len, kv.data(), B * 4, hipMemcpyHostToDevice));
+  GSV_HIP(hipMemcpy(h->d_active, zero.data(), B * 4, hipMemcpyHostToDevice));
+  GSV_HIP(hipMemset(h->ybuf, 0, (size_t)B * h->cfg.dim * 4));
+  GSV_HIP(hipMemset(h->kv, 0, (size_t)h->cfg.n_layer * 2 * h->kv_layer_stride * esz(h)));
+  h->B = B;
+  return GSV_OK;
 }
 
 int gsv_op_sample(const float* logits, int B, int vocab, int vocab_eff, const int32_t* prev, int prev_len,

@@ -60,6 +60,7 @@ _SIGS = {
                                  C.POINTER(C.c_int), C.c_void_p]),
     "gsv_t2s_debug_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsv_t2s_time_step": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]),
+    "gsv_t2s_debug_set_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gsv_t2s_step_bytes": (C.c_int64, [C.c_void_p, C.POINTER(C.c_int64)]),
     "gsv_vits_create": (C.c_int, [C.POINTER(VitsConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "gsv_vits_destroy": (None, [C.c_void_p]),

@@ -95,6 +95,8 @@ int gsv_t2s_debug_logits(gsv_t2s_t* h, float* out, gsv_stream_t stream);
 /* per-kernel timing of the decode step: average device time (ms) of one step over `iters`
  * replays at the current cache length, and of the decode-attention kernel alone. */
 int gsv_t2s_time_step(gsv_t2s_t* h, int iters, float* step_ms, float* attn_ms, gsv_stream_t stream);
+/* measurement hook: B rows with kv_len cached positions each (zeroed cache), for kernel timing sweeps */
+int gsv_t2s_debug_set_state(gsv_t2s_t* h, int B, int kv_len);
 /* algorithmic HBM bytes of one decode step at the current state */
 int64_t gsv_t2s_step_bytes(gsv_t2s_t* h, int64_t* attn_bytes);
 
