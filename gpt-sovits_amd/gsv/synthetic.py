@@ -433,3 +433,57 @@ def make_vocoder_state_dict(cfg: dict, seed: int = 0) -> "OrderedDict[str, torch
         sd["conv_post.weight"] = _w("voc.conv_post.weight", (1, ch, 7), ch * 7, 0.3, seed)
         sd["conv_post.bias"] = _b("voc.conv_post.bias", 1, 0.05, seed)
     return sd
+
+
+# --------------------------------------------------------------------------
+# v3 / v4 flow-matching DiT (H14)
+# --------------------------------------------------------------------------
+DIT_V3_CONFIG = {"dim": 1024, "depth": 22, "heads": 16, "dim_head": 64, "ff_mult": 2, "mel_dim": 100, "text_dim": 512,
+                 "conv_layers": 4}   # reference module/models.py:1219-1222
+
+
+def small_dit_config():
+    return {"dim": 128, "depth": 2, "heads": 2, "dim_head": 64, "ff_mult": 2, "mel_dim": 100, "text_dim": 64,
+            "conv_layers": 2}
+
+
+def make_dit_state_dict(cfg: dict, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """DiT state dict (reference f5_tts/model/backbones/dit.py; keys as under `cfm.estimator.`)."""
+    D, td, md = cfg["dim"], cfg["text_dim"], cfg["mel_dim"]
+    inner = cfg["heads"] * cfg["dim_head"]
+    sd = OrderedDict()
+
+    def lin(name, o, i, gain=1.0):
+        sd[name + ".weight"] = _w("dit." + name + ".weight", (o, i), i, gain, seed)
+        sd[name + ".bias"] = _b("dit." + name + ".bias", o, 0.05, seed)
+
+    for nm in ("time_embed", "d_embed"):
+        lin(nm + ".time_mlp.0", D, 256)
+        lin(nm + ".time_mlp.2", D, D)
+    for i in range(cfg["conv_layers"]):
+        p = f"text_embed.text_blocks.{i}."
+        sd[p + "dwconv.weight"] = _w("dit." + p + "dwconv.weight", (td, 1, 7), 7, 1.0, seed)
+        sd[p + "dwconv.bias"] = _b("dit." + p + "dwconv.bias", td, 0.05, seed)
+        sd[p + "norm.weight"] = 1.0 + hash_symmetric("dit." + p + "norm.weight", (td,), 0.1, seed)
+        sd[p + "norm.bias"] = _b("dit." + p + "norm.bias", td, 0.1, seed)
+        lin(p + "pwconv1", 2 * td, td)
+        sd[p + "grn.gamma"] = hash_symmetric("dit." + p + "grn.gamma", (1, 1, 2 * td), 0.3, seed)
+        sd[p + "grn.beta"] = hash_symmetric("dit." + p + "grn.beta", (1, 1, 2 * td), 0.1, seed)
+        lin(p + "pwconv2", td, 2 * td)
+    lin("input_embed.proj", D, 2 * md + td)
+    for j in (0, 2):
+        n = f"input_embed.conv_pos_embed.conv1d.{j}"
+        sd[n + ".weight"] = _w("dit." + n + ".weight", (D, D // 16, 31), (D // 16) * 31, 1.0, seed)
+        sd[n + ".bias"] = _b("dit." + n + ".bias", D, 0.05, seed)
+    for i in range(cfg["depth"]):
+        p = f"transformer_blocks.{i}."
+        lin(p + "attn_norm.linear", 6 * D, D, 0.5)
+        lin(p + "attn.to_q", inner, D)
+        lin(p + "attn.to_k", inner, D)
+        lin(p + "attn.to_v", inner, D)
+        lin(p + "attn.to_out.0", D, inner)
+        lin(p + "ff.ff.0.0", D * cfg["ff_mult"], D)
+        lin(p + "ff.ff.2", D, D * cfg["ff_mult"])
+    lin("norm_out.linear", 2 * D, D, 0.5)
+    lin("proj_out", md, D)
+    return sd

@@ -93,3 +93,24 @@ def voc_case_inputs(case):
     sd = S.make_vocoder_state_dict(cfg, seed=case["seed"])
     mel = S.hash_symmetric("voc_mel", (1, 100, case["F"]), 2.0, case["seed"])
     return cfg, sd, mel
+
+
+CFM_CASES = {
+    "cfm_small": dict(cfg="small", seed=1, B=1, T=40, Tp=12, steps=4),
+    "cfm_small_b2": dict(cfg="small", seed=2, B=2, T=33, Tp=9, steps=3),
+    "cfm_v3dims": dict(cfg="v3x2", seed=3, B=1, T=36, Tp=10, steps=2),      # v3 widths, depth 2
+}
+
+
+def cfm_case_inputs(case):
+    if case["cfg"] == "small":
+        cfg = S.small_dit_config()
+    else:
+        cfg = dict(S.DIT_V3_CONFIG)
+        cfg["depth"] = 2
+    sd = S.make_dit_state_dict(cfg, seed=case["seed"])
+    B, T, Tp = case["B"], case["T"], case["Tp"]
+    mu = S.hash_symmetric("cfm_mu", (B, T, cfg["text_dim"]), 1.0, case["seed"])
+    prompt = S.hash_symmetric("cfm_prompt", (B, cfg["mel_dim"], Tp), 1.0, case["seed"])
+    noise = S.hash_normal("cfm_noise", (B, cfg["mel_dim"], T), case["seed"])
+    return cfg, sd, mu, prompt, noise

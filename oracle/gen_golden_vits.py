@@ -129,3 +129,30 @@ def gen_voc():
               f"oracle max-abs err {err:.2e}")
         assert err <= 1e-4
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), wav=ref.numpy().astype(np.float32))
+
+
+def gen_cfm():
+    """CFM.inference over the reference DiT (with the restated rotary embedding, oracle/rope.py) vs the oracle."""
+    from oracle.cases import CFM_CASES, cfm_case_inputs
+    from oracle import cfm_oracle
+    ref_import.setup()
+    from GPT_SoVITS.f5_tts.model.backbones.dit import DiT
+    from module.models import CFM
+    for name, case in CFM_CASES.items():
+        cfg, sd, mu, prompt, noise = cfm_case_inputs(case)
+        dit = DiT(dim=cfg["dim"], depth=cfg["depth"], heads=cfg["heads"], dim_head=cfg["dim_head"], ff_mult=cfg["ff_mult"],
+                  mel_dim=cfg["mel_dim"], text_dim=cfg["text_dim"], conv_layers=cfg["conv_layers"])
+        res = dit.load_state_dict(sd, strict=True)
+        cfm = CFM(cfg["mel_dim"], dit).eval()
+        orig = torch.randn
+        torch.randn = lambda *a, **k: noise.clone()
+        try:
+            ref = cfm.inference(mu, torch.LongTensor([case["T"]] * case["B"]), prompt, case["steps"], inference_cfg_rate=0)
+        finally:
+            torch.randn = orig
+        out = cfm_oracle.cfm_inference(sd, cfg, mu, prompt, case["steps"], noise.clone())
+        err = (out - ref).abs().max().item()
+        print(f"[gen_golden] {name}: out {tuple(ref.shape)} absmax {ref.abs().max():.3f} rms {ref.pow(2).mean().sqrt():.3f} "
+              f"oracle max-abs err {err:.2e}")
+        assert err <= 2e-4
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), mel=ref.numpy().astype(np.float32))

@@ -49,8 +49,14 @@ def setup():
         _stub("torchmetrics")
         _stub("torchmetrics.classification", MulticlassAccuracy=_Dummy)
     if "x_transformers" not in sys.modules:
+        # x_transformers is an un-vendored, un-pinned dependency of the reference (requirements.txt:38):
+        # its RotaryEmbedding / apply_rotary_pos_emb are RESTATED in oracle/rope.py from the library's
+        # published definition, so everything the reference's DiT computes with them is "parity unpinned"
+        # with respect to the real library.
+        from oracle import rope
         _stub("x_transformers")
-        _stub("x_transformers.x_transformers", RotaryEmbedding=_Dummy, apply_rotary_pos_emb=None)
+        _stub("x_transformers.x_transformers", RotaryEmbedding=rope.RotaryEmbedding,
+              apply_rotary_pos_emb=rope.apply_rotary_pos_emb)
     if "torchaudio" not in sys.modules:
         ta = _stub("torchaudio")
         ta.transforms = _stub("torchaudio.transforms", MelSpectrogram=_Dummy)
