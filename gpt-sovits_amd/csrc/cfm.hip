@@ -1,0 +1,487 @@
+// v3 / v4 flow-matching mel decoder (H14) for gfx950: CFM.inference (reference module/models.py:1027-1085)
+// over the DiT estimator (reference f5_tts/model/backbones/dit.py:88-194, f5_tts/model/modules.py).
+//
+// Layout: one utterance at a time, every activation channels-last [frame][channel] in the engine dtype,
+// the Euler state x and the velocity in fp32.  Every Linear / conv is one call of the MFMA GEMM / implicit-GEMM
+// kernels (conv_lds.hip / conv_gemm.hip); the grouped position conv is a Z=16 batched implicit GEMM.
+// Everything that depends only on the step index is hoisted out of the Euler loop: the time embeddings of all
+// n steps are computed at once and pushed through every block's AdaLN-Zero modulation Linear as ONE [n][dim] x
+// [dim][6 dim] GEMM per block (the reference re-reads those 22 x 6 dim x dim weights as a GEMV every step);
+// the text embedding (ConvNeXt-V2 stack), the rotary table and the prompt / text columns of the input
+// concatenation are built once per utterance (the reference caches the first two the same way, models.py:1046-1062).
+// Gate * (W a + b) + residual is the GEMM epilogue (ConvArgs::gate), GELU / Mish too.
+#include "engine.h"
+
+using namespace gsv;
+using namespace gsveng;
+
+namespace gsv {
+
+// sinusoidal embedding (modules.py:152-164) of `rows` scalars: [rows][2*half] = sin | cos of 1000 * t * exp(-j * ln(1e4)/(half-1))
+__global__ void cfm_sinus_kernel(const float* __restrict__ tvals, int rows, int half, float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * half) return;
+  int r = i / half, j = i - r * half;
+  const float e = expf((float)j * -(logf(10000.f) / (float)(half - 1)));
+  const float a = 1000.f * tvals[r] * e;
+  out[(long long)r * 2 * half + j] = sinf(a);
+  out[(long long)r * 2 * half + half + j] = cosf(a);
+}
+
+// out[r][c] = silu(a[r][c] + b[r][c])   (time + step-size embedding, then the SiLU of AdaLayerNormZero)
+template <typename T>
+__global__ void cfm_add_silu_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, T* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float u = a[i] + b[i];
+  out[i] = (T)(u / (1.f + expf(-u)));
+}
+
+// fp32 -> engine dtype with a row stride on both sides
+template <typename T>
+__global__ void cfm_cast_rows_kernel(const float* __restrict__ src, int lds, int rows, int C, T* __restrict__ dst, int ldd, int col0) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * C) return;
+  int r = (int)(i / C), c = (int)(i - (long long)r * C);
+  dst[(long long)r * ldd + col0 + c] = (T)src[(long long)r * lds + c];
+}
+
+// te0[t][c] = mu[t][c] + table[min(t, 4095)][c]   (TextEmbedding.forward, dit.py:50-72)
+template <typename T>
+__global__ void cfm_text_pos_kernel(const float* __restrict__ mu, const float* __restrict__ table, int Tn, int C, T* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Tn * C) return;
+  int t = (int)(i / C), c = (int)(i - (long long)t * C);
+  out[i] = (T)(mu[i] + table[(long long)min(t, 4095) * C + c]);
+}
+
+// depthwise conv, 7 taps, zero padding 3 (ConvNeXtV2Block.dwconv, modules.py:250)
+template <typename T>
+__global__ void cfm_dwconv7_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, int Tn, int C,
+                                   T* __restrict__ y) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Tn * C) return;
+  int t = (int)(i / C), c = (int)(i - (long long)t * C);
+  float acc = b[c];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    int ti = t + j - 3;
+    if (ti >= 0 && ti < Tn) acc += w[c * 7 + j] * to_f(x[(long long)ti * C + c]);
+  }
+  y[i] = (T)acc;
+}
+
+// GRN (modules.py:225-236): gx[c] = ||y[:, c]||_2 over time
+template <typename T>
+__global__ void cfm_grn_norm_kernel(const T* __restrict__ y, int Tn, int C, float* __restrict__ gx) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (int t = part; t < Tn; t += 4) { float v = to_f(y[(long long)t * C + c]); s += v * v; }
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && c < C) gx[c] = sqrtf(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// y = gamma * (y * gx / (mean_c gx + 1e-6)) + beta + y
+template <typename T>
+__global__ void cfm_grn_apply_kernel(T* __restrict__ y, const float* __restrict__ gx, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, int Tn, int C) {
+  __shared__ float wsum[4];
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) s += gx[c];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float mean = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)C;
+  const float inv = 1.f / (mean + 1e-6f);
+  const long long n = (long long)Tn * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    int c = (int)(i % C);
+    float v = to_f(y[i]);
+    y[i] = (T)(gamma[c] * (v * (gx[c] * inv)) + beta[c] + v);
+  }
+}
+
+// AdaLN-Zero modulation: y = LN(x) * (1 + scale) + shift, LN without affine, eps 1e-6 (modules.py:275-312).  One wave per row.
+template <typename T>
+__global__ void cfm_ln_mod_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int rows,
+                                  int C, T* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (long long)row * C;
+  float sum = 0.f;
+  for (int c = lane; c < C; c += 64) sum += to_f(xr[c]);
+  const float mean = wave_sum(sum) / (float)C;
+  float var = 0.f;
+  for (int c = lane; c < C; c += 64) { float d = to_f(xr[c]) - mean; var += d * d; }
+  const float rstd = rsqrtf(wave_sum(var) / (float)C + 1e-6f);
+  T* yr = y + (long long)row * C;
+  for (int c = lane; c < C; c += 64) yr[c] = (T)((to_f(xr[c]) - mean) * rstd * (1.f + scale[c]) + shift[c]);
+}
+
+// rotary embedding on the first 2*half channels of the q and k projections (x_transformers' apply_rotary_pos_emb on the
+// un-split [n, heads*dim_head] tensors, modules.py:420-427): adjacent pairs, angle = t * inv_freq[pair]
+template <typename T>
+__global__ void cfm_rope_kernel(T* __restrict__ qkv, int ld, int kcol0, int Tn, int half, const float* __restrict__ cs) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Tn * half * 2) return;
+  const int which = i / (Tn * half);
+  const int r = i - which * Tn * half;
+  const int t = r / half, p = r - t * half;
+  T* v = qkv + (long long)t * ld + (which ? kcol0 : 0) + 2 * p;
+  const float c = cs[((long long)t * half + p) * 2], s = cs[((long long)t * half + p) * 2 + 1];
+  const float a = to_f(v[0]), b = to_f(v[1]);
+  v[0] = (T)(a * c - b * s);
+  v[1] = (T)(b * c + a * s);
+}
+
+__global__ void cfm_rope_table_kernel(int Tn, int half, float* __restrict__ cs) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Tn * half) return;
+  const int t = i / half, p = i - t * half;
+  const float inv = 1.f / powf(10000.f, (float)(2 * p) / (float)(2 * half));
+  const float ang = (float)t * inv;
+  cs[2 * (long long)i] = cosf(ang);
+  cs[2 * (long long)i + 1] = sinf(ang);
+}
+
+__device__ __forceinline__ unsigned long long cfm_mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// x0[t][c] = temperature * noise (given channels-first [C][Tn], or a counter-based normal draw), zero on the prompt rows
+__global__ void cfm_init_x_kernel(const float* __restrict__ noise, unsigned long long seed, float temperature, int Tn, int Tp, int C,
+                                  float* __restrict__ x) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Tn * C) return;
+  int t = (int)(i / C), c = (int)(i - (long long)t * C);
+  float n;
+  if (noise) n = noise[(long long)c * Tn + t];
+  else {
+    unsigned long long h1 = cfm_mix64(seed ^ cfm_mix64((unsigned long long)i * 2 + 1)), h2 = cfm_mix64(seed ^ cfm_mix64((unsigned long long)i * 2 + 2));
+    float u1 = ((float)(h1 >> 40) + 1.f) * (1.f / 16777217.f), u2 = (float)(h2 >> 40) * (1.f / 16777216.f);
+    n = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+  }
+  x[i] = t < Tp ? 0.f : n * temperature;
+}
+
+// Euler update x += d * v (rows >= Tp; prompt rows stay 0, models.py:1083-1084) and refresh the x columns of the DiT input
+template <typename T>
+__global__ void cfm_euler_kernel(float* __restrict__ x, const float* __restrict__ v, float d, int Tn, int Tp, int C, T* __restrict__ xin,
+                                 int ldin) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Tn * C) return;
+  int t = (int)(i / C), c = (int)(i - (long long)t * C);
+  float u = t < Tp ? 0.f : x[i] + (v ? d * v[i] : 0.f);
+  x[i] = u;
+  xin[(long long)t * ldin + c] = (T)u;
+}
+
+// prompt mel (channels-first [C][Tp]) -> the cond columns of the DiT input, zero after the prompt; also zeroes the pad columns
+template <typename T>
+__global__ void cfm_cond_kernel(const float* __restrict__ prompt, int Tn, int Tp, int C, T* __restrict__ xin, int ldin, int col0,
+                                int pad0) {
+  const int W = C + (ldin - pad0);
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Tn * W) return;
+  int t = (int)(i / W), c = (int)(i - (long long)t * W);
+  if (c < C) xin[(long long)t * ldin + col0 + c] = (T)(t < Tp ? prompt[(long long)c * Tp + t] : 0.f);
+  else xin[(long long)t * ldin + pad0 + (c - C)] = (T)0.f;
+}
+
+template <typename T>
+__global__ void cfm_copy_cols_kernel(const T* __restrict__ src, int lds, int rows, int C, T* __restrict__ dst, int ldd, int col0) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * C) return;
+  int r = (int)(i / C), c = (int)(i - (long long)r * C);
+  dst[(long long)r * ldd + col0 + c] = src[(long long)r * lds + c];
+}
+
+// channels-last fp32 [Tn][C] -> channels-first [C][Tn]
+__global__ void cfm_out_kernel(const float* __restrict__ x, int Tn, int C, float* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Tn * C) return;
+  int c = (int)(i / Tn), t = (int)(i - (long long)c * Tn);
+  out[i] = x[(long long)t * C + c];
+}
+
+}  // namespace gsv
+
+struct DitBlockW { Conv mod, qkv, out, ff1, ff2; };
+struct TextBlockW { float *dw = nullptr, *db = nullptr, *ng = nullptr, *nb = nullptr, *gg = nullptr, *gb = nullptr; Conv pw1, pw2; };
+
+struct gsv_cfm {
+  gsv_vits ctx;
+  gsv_dit_config cfg;
+  bool finalized = false;
+  int ldin = 0;
+  Conv t0, t2, d0, d2, in_proj, pos1, pos2, final_mod, proj_out;
+  std::vector<TextBlockW> text;
+  std::vector<DitBlockW> blocks;
+  float* pos_table = nullptr;   // fp32 [4096][text_dim]
+};
+
+#define CFM_LAUNCH(kern, n, ...)                                                                         \
+  do {                                                                                                   \
+    hipLaunchKernelGGL(kern, dim3(nblk((long long)(n))), dim3(256), 0, s, __VA_ARGS__);                 \
+    GSV_HIP(hipGetLastError());                                                                          \
+  } while (0)
+
+namespace {
+
+// time-independent precomputation for all n steps: mods[l][i][6D] (l < depth) and mods[depth][i][2D]
+template <typename T>
+int cfm_modulations(gsv_cfm* c, hipStream_t s, int N, float** mods_out) {
+  gsv_vits* h = &c->ctx;
+  const auto& g = c->cfg;
+  const int D = g.dim;
+  const size_t es = sizeof(T);
+  float *tvals, *sinus, *temb, *mods;
+  void *sin_t, *mid_t, *stemb;
+  GSV_RC(need(h, "cfm_tvals", (size_t)2 * N * 4, (void**)&tvals));
+  GSV_RC(need(h, "cfm_sinus", (size_t)2 * N * 256 * 4, (void**)&sinus));
+  GSV_RC(need(h, "cfm_sin_t", (size_t)2 * N * 256 * es, &sin_t));
+  GSV_RC(need(h, "cfm_mid_t", (size_t)2 * N * D * es, &mid_t));
+  GSV_RC(need(h, "cfm_temb", (size_t)2 * N * D * 4, (void**)&temb));
+  GSV_RC(need(h, "cfm_stemb", (size_t)N * D * es, &stemb));
+  GSV_RC(need(h, "cfm_mods", ((size_t)g.depth * 6 + 2) * N * D * 4, (void**)&mods));
+  {
+    std::vector<float> tv(2 * N);
+    double t = 0.0;
+    const double d = 1.0 / N;
+    for (int i = 0; i < N; ++i) { tv[i] = (float)t; tv[N + i] = (float)d; t += d; }   // models.py:1042-1082
+    GSV_HIP(hipMemcpyAsync(tvals, tv.data(), tv.size() * 4, hipMemcpyHostToDevice, s));
+    GSV_HIP(hipStreamSynchronize(s));   // tv lives on this stack frame
+  }
+  CFM_LAUNCH(cfm_sinus_kernel, 2 * N * 128, tvals, 2 * N, 128, sinus);
+  CFM_LAUNCH(cfm_cast_rows_kernel<T>, 2 * N * 256, sinus, 256, 2 * N, 256, (T*)sin_t, 256, 0);
+  ConvOpt o1; o1.post_act = ACT_SILU;
+  ConvOpt o2; o2.out_f32 = 1;
+  // rows [0, N): time_embed(t_i); rows [N, 2N): d_embed(d)   (dit.py:149-153)
+  GSV_RC(conv(h, s, c->t0, sin_t, 256, N, mid_t, N, o1));
+  GSV_RC(conv(h, s, c->t2, mid_t, D, N, temb, N, o2));
+  GSV_RC(conv(h, s, c->d0, (const T*)sin_t + (size_t)N * 256, 256, N, (T*)mid_t + (size_t)N * D, N, o1));
+  GSV_RC(conv(h, s, c->d2, (const T*)mid_t + (size_t)N * D, D, N, temb + (size_t)N * D, N, o2));
+  CFM_LAUNCH(cfm_add_silu_kernel<T>, (long long)N * D, temb, temb + (size_t)N * D, (long long)N * D, (T*)stemb);
+  for (int l = 0; l < g.depth; ++l)
+    GSV_RC(conv(h, s, c->blocks[l].mod, stemb, D, N, mods + (size_t)l * N * 6 * D, N, o2));
+  GSV_RC(conv(h, s, c->final_mod, stemb, D, N, mods + (size_t)g.depth * N * 6 * D, N, o2));
+  *mods_out = mods;
+  return GSV_OK;
+}
+
+// one utterance: mu [T][text_dim] fp32, prompt [mel][Tp] fp32, noise [mel][T] fp32 or null -> out [mel][T] fp32
+template <typename T>
+int cfm_infer_one(gsv_cfm* c, hipStream_t s, const float* mods, const float* mu, const float* prompt, int Tn, int Tp, int N,
+                  const float* noise, float temperature, unsigned long long seed, float* out) {
+  gsv_vits* h = &c->ctx;
+  const auto& g = c->cfg;
+  const int D = g.dim, td = g.text_dim, md = g.mel_dim, inner = g.heads * g.dim_head, FF = D * g.ff_mult, ldin = c->ldin;
+  const int half = g.dim_head / 2;
+  const size_t es = sizeof(T);
+  float *x, *v, *cs, *gx;
+  void *xin, *ta, *tb, *tw, *hb, *c1, *nrm, *qkv, *ao, *ff;
+  GSV_RC(need(h, "cfm_x", (size_t)Tn * md * 4, (void**)&x));
+  GSV_RC(need(h, "cfm_v", (size_t)Tn * md * 4, (void**)&v));
+  GSV_RC(need(h, "cfm_cs", (size_t)Tn * half * 2 * 4, (void**)&cs));
+  GSV_RC(need(h, "cfm_gx", (size_t)2 * td * 4, (void**)&gx));
+  GSV_RC(need(h, "cfm_xin", (size_t)Tn * ldin * es, &xin));
+  GSV_RC(need(h, "cfm_ta", (size_t)Tn * td * es, &ta));
+  GSV_RC(need(h, "cfm_tb", (size_t)Tn * td * es, &tb));
+  GSV_RC(need(h, "cfm_tw", (size_t)Tn * 2 * td * es, &tw));
+  GSV_RC(need(h, "cfm_h", (size_t)Tn * D * es, &hb));
+  GSV_RC(need(h, "cfm_c1", (size_t)Tn * D * es, &c1));
+  GSV_RC(need(h, "cfm_nrm", (size_t)Tn * D * es, &nrm));
+  GSV_RC(need(h, "cfm_qkv", (size_t)Tn * 3 * inner * es, &qkv));
+  GSV_RC(need(h, "cfm_ao", (size_t)Tn * inner * es, &ao));
+  GSV_RC(need(h, "cfm_ff", (size_t)Tn * FF * es, &ff));
+
+  // ---- per-utterance constants: text embedding (dit.py:50-72), cond columns, rotary table
+  CFM_LAUNCH(cfm_text_pos_kernel<T>, (long long)Tn * td, mu, c->pos_table, Tn, td, (T*)ta);
+  for (auto& b : c->text) {
+    CFM_LAUNCH(cfm_dwconv7_kernel<T>, (long long)Tn * td, (const T*)ta, b.dw, b.db, Tn, td, (T*)tb);
+    GSV_RC(launch_layernorm(h->dtype, tb, 0, nullptr, 0, b.ng, b.nb, tb, 0, Tn, td, 1e-6f, s));
+    ConvOpt og; og.post_act = ACT_GELU;
+    GSV_RC(conv(h, s, b.pw1, tb, td, Tn, tw, Tn, og));
+    hipLaunchKernelGGL(cfm_grn_norm_kernel<T>, dim3(cdiv(2 * td, 64)), dim3(256), 0, s, (const T*)tw, Tn, 2 * td, gx);
+    hipLaunchKernelGGL(cfm_grn_apply_kernel<T>, dim3(std::min(1024, nblk((long long)Tn * 2 * td))), dim3(256), 0, s, (T*)tw, gx, b.gg,
+                       b.gb, Tn, 2 * td);
+    GSV_HIP(hipGetLastError());
+    ConvOpt orr; orr.res = ta;
+    GSV_RC(conv(h, s, b.pw2, tw, 2 * td, Tn, ta, Tn, orr));
+  }
+  {
+    const int W = md + (ldin - (2 * md + td));
+    CFM_LAUNCH(cfm_cond_kernel<T>, (long long)Tn * W, prompt, Tn, Tp, md, (T*)xin, ldin, md, 2 * md + td);
+    hipLaunchKernelGGL((cfm_copy_cols_kernel<T>), dim3(nblk((long long)Tn * td)), dim3(256), 0, s, (const T*)ta, td, Tn, td, (T*)xin,
+                       ldin, 2 * md);
+    GSV_HIP(hipGetLastError());
+  }
+  CFM_LAUNCH(cfm_rope_table_kernel, Tn * half, Tn, half, cs);
+  CFM_LAUNCH(cfm_init_x_kernel, (long long)Tn * md, noise, seed, temperature, Tn, Tp, md, x);
+  CFM_LAUNCH(cfm_euler_kernel<T>, (long long)Tn * md, x, (const float*)nullptr, 0.f, Tn, Tp, md, (T*)xin, ldin);
+
+  const float d = (float)(1.0 / N);
+  const float att_scale = 1.f / sqrtf((float)g.dim_head);
+  for (int step = 0; step < N; ++step) {
+    // ---- InputEmbedding (dit.py:75-84): proj(cat(x, cond, text)) then + ConvPositionEmbedding
+    ConvOpt o;
+    GSV_RC(conv(h, s, c->in_proj, xin, ldin, Tn, hb, Tn, o));
+    {
+      ConvArgs a;
+      const int cg = D / 16;
+      a.x = hb; a.w = c->pos1.w; a.bias = c->pos1.b; a.y = c1;
+      a.T_in = Tn; a.T_out = Tn; a.T_virt = Tn; a.Cin = cg; a.Cout = cg; a.taps = 31; a.pad = 15;
+      a.ldx = D; a.ldw = 31 * cg; a.ldy = D; a.ldr = D; a.post_act = ACT_MISH;
+      a.Z = 16; a.xz = cg; a.wz = (long long)cg * 31 * cg; a.yz = cg; a.bz = cg;
+      GSV_RC(launch_conv_gemm(h->dtype, a, s));
+      a.x = c1; a.w = c->pos2.w; a.bias = c->pos2.b; a.y = hb; a.accumulate = 1;   // h += mish(conv2(.))
+      GSV_RC(launch_conv_gemm(h->dtype, a, s));
+    }
+    // ---- DiT blocks (modules.py:550-594)
+    for (int l = 0; l < g.depth; ++l) {
+      const DitBlockW& b = c->blocks[l];
+      const float* m = mods + ((size_t)l * N + step) * 6 * D;   // shift_a, scale_a, gate_a, shift_m, scale_m, gate_m
+      hipLaunchKernelGGL(cfm_ln_mod_kernel<T>, dim3(cdiv(Tn, 4)), dim3(256), 0, s, (const T*)hb, m + D, m, Tn, D, (T*)nrm);
+      GSV_RC(conv(h, s, b.qkv, nrm, D, Tn, qkv, Tn, o));
+      CFM_LAUNCH(cfm_rope_kernel<T>, Tn * half * 2, (T*)qkv, 3 * inner, inner, Tn, half, cs);
+      GSV_RC(attention(h, s, qkv, 3 * inner, 0, qkv, 3 * inner, inner, 2 * inner, Tn, Tn, g.heads, g.dim_head, att_scale, nullptr,
+                       nullptr, ao, inner));
+      ConvOpt og; og.gate = m + 2 * D; og.res = hb;
+      GSV_RC(conv(h, s, b.out, ao, inner, Tn, hb, Tn, og));
+      hipLaunchKernelGGL(cfm_ln_mod_kernel<T>, dim3(cdiv(Tn, 4)), dim3(256), 0, s, (const T*)hb, m + 4 * D, m + 3 * D, Tn, D, (T*)nrm);
+      ConvOpt of; of.post_act = ACT_GELU_TANH;
+      GSV_RC(conv(h, s, b.ff1, nrm, D, Tn, ff, Tn, of));
+      ConvOpt o2; o2.gate = m + 5 * D; o2.res = hb;
+      GSV_RC(conv(h, s, b.ff2, ff, FF, Tn, hb, Tn, o2));
+    }
+    // ---- AdaLayerNormZero_Final (scale, shift) + proj_out, then the Euler step (models.py:1080-1084)
+    const float* mf = mods + (size_t)g.depth * N * 6 * D + (size_t)step * 2 * D;
+    hipLaunchKernelGGL(cfm_ln_mod_kernel<T>, dim3(cdiv(Tn, 4)), dim3(256), 0, s, (const T*)hb, mf, mf + D, Tn, D, (T*)nrm);
+    ConvOpt ov; ov.out_f32 = 1;
+    GSV_RC(conv(h, s, c->proj_out, nrm, D, Tn, v, Tn, ov));
+    CFM_LAUNCH(cfm_euler_kernel<T>, (long long)Tn * md, x, (const float*)v, d, Tn, Tp, md, (T*)xin, ldin);
+  }
+  CFM_LAUNCH(cfm_out_kernel, (long long)Tn * md, x, Tn, md, out);
+  return GSV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsv_cfm_create(const gsv_dit_config* cfg, int dtype, gsv_cfm_t** out) {
+  GSV_REQUIRE(cfg && out, "cfm_create: null argument");
+  GSV_REQUIRE(dtype == GSV_F16 || dtype == GSV_F32, "cfm_create: bad dtype");
+  GSV_REQUIRE(cfg->dim > 0 && cfg->dim % 16 == 0 && (cfg->dim / 16) % 8 == 0, "cfm_create: dim=%d must be a multiple of 128", cfg->dim);
+  GSV_REQUIRE(cfg->dim_head % 16 == 0 && cfg->heads > 0 && cfg->depth > 0, "cfm_create: bad head configuration");
+  GSV_REQUIRE(cfg->text_dim % 8 == 0 && cfg->mel_dim % 4 == 0 && cfg->ff_mult > 0 && cfg->conv_layers >= 0, "cfm_create: bad dims");
+  int n = 0;
+  GSV_HIP(hipGetDeviceCount(&n));
+  gsv_cfm* c = new gsv_cfm();
+  c->cfg = *cfg;
+  c->ctx.dtype = dtype;
+  *out = c;
+  return GSV_OK;
+}
+
+void gsv_cfm_destroy(gsv_cfm_t* c) {
+  if (!c) return;
+  free_ctx(&c->ctx);
+  delete c;
+}
+
+int gsv_cfm_load_tensor(gsv_cfm_t* c, const char* name, const float* data, int64_t numel) {
+  GSV_REQUIRE(c && name && data && numel > 0, "cfm_load_tensor: bad argument");
+  GSV_REQUIRE(!c->finalized, "cfm_load_tensor: handle already finalized");
+  c->ctx.staged[name].assign(data, data + numel);
+  return GSV_OK;
+}
+
+int gsv_cfm_finalize(gsv_cfm_t* c) {
+  GSV_REQUIRE(c && !c->finalized, "cfm_finalize: bad handle");
+  gsv_vits* h = &c->ctx;
+  const auto& g = c->cfg;
+  const int D = g.dim, td = g.text_dim, md = g.mel_dim, inner = g.heads * g.dim_head;
+  GSV_RC(make_conv(h, "time_embed.time_mlp.0", D, 256, 1, true, &c->t0));
+  GSV_RC(make_conv(h, "time_embed.time_mlp.2", D, D, 1, true, &c->t2));
+  GSV_RC(make_conv(h, "d_embed.time_mlp.0", D, 256, 1, true, &c->d0));
+  GSV_RC(make_conv(h, "d_embed.time_mlp.2", D, D, 1, true, &c->d2));
+  c->text.resize(g.conv_layers);
+  for (int i = 0; i < g.conv_layers; ++i) {
+    const std::string p = "text_embed.text_blocks." + std::to_string(i) + ".";
+    TextBlockW& b = c->text[i];
+    GSV_RC(make_vec(h, p + "dwconv.weight", (size_t)td * 7, &b.dw));
+    GSV_RC(make_vec(h, p + "dwconv.bias", td, &b.db));
+    GSV_RC(make_vec(h, p + "norm.weight", td, &b.ng));
+    GSV_RC(make_vec(h, p + "norm.bias", td, &b.nb));
+    GSV_RC(make_conv(h, p + "pwconv1", 2 * td, td, 1, true, &b.pw1));
+    GSV_RC(make_vec(h, p + "grn.gamma", (size_t)2 * td, &b.gg));
+    GSV_RC(make_vec(h, p + "grn.beta", (size_t)2 * td, &b.gb));
+    GSV_RC(make_conv(h, p + "pwconv2", td, 2 * td, 1, true, &b.pw2));
+  }
+  const int cin = 2 * md + td;
+  c->ldin = (cin + 31) / 32 * 32;
+  GSV_RC(make_conv_padded(h, "input_embed.proj", D, cin, c->ldin, 1, true, &c->in_proj));
+  GSV_RC(make_conv(h, "input_embed.conv_pos_embed.conv1d.0", D, D / 16, 31, true, &c->pos1));
+  GSV_RC(make_conv(h, "input_embed.conv_pos_embed.conv1d.2", D, D / 16, 31, true, &c->pos2));
+  c->blocks.resize(g.depth);
+  for (int i = 0; i < g.depth; ++i) {
+    const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+    DitBlockW& b = c->blocks[i];
+    GSV_RC(make_conv(h, p + "attn_norm.linear", 6 * D, D, 1, true, &b.mod));
+    GSV_RC(make_stacked(h, {p + "attn.to_q", p + "attn.to_k", p + "attn.to_v"}, inner, D, &b.qkv));
+    GSV_RC(make_conv(h, p + "attn.to_out.0", D, inner, 1, true, &b.out));
+    GSV_RC(make_conv(h, p + "ff.ff.0.0", D * g.ff_mult, D, 1, true, &b.ff1));
+    GSV_RC(make_conv(h, p + "ff.ff.2", D, D * g.ff_mult, 1, true, &b.ff2));
+  }
+  GSV_RC(make_conv(h, "norm_out.linear", 2 * D, D, 1, true, &c->final_mod));
+  GSV_RC(make_conv(h, "proj_out", md, D, 1, true, &c->proj_out));
+  // precompute_freqs_cis(text_dim, 4096) (modules.py:127-137): [pos][cos(pos f_j) | sin(pos f_j)]
+  {
+    std::vector<float> tab((size_t)4096 * td);
+    const int half = td / 2;
+    std::vector<float> fr(half);
+    for (int j = 0; j < half; ++j) fr[j] = 1.0f / powf(10000.0f, (float)(2 * j) / (float)td);
+    for (int p = 0; p < 4096; ++p)
+      for (int j = 0; j < half; ++j) {
+        const float a = (float)p * fr[j];
+        tab[(size_t)p * td + j] = cosf(a);
+        tab[(size_t)p * td + half + j] = sinf(a);
+      }
+    GSV_RC(up_f32(h, tab.data(), tab.size(), &c->pos_table));
+  }
+  h->staged.clear();
+  c->finalized = true;
+  return GSV_OK;
+}
+
+int gsv_cfm_inference(gsv_cfm_t* c, const float* mu, const float* prompt, int B, int T, int Tp, int n_steps, const float* noise,
+                      float temperature, uint64_t seed, float* out, gsv_stream_t stream) {
+  GSV_REQUIRE(c && c->finalized, "cfm_inference: handle not finalized");
+  GSV_REQUIRE(mu && out && B > 0 && T > 0 && n_steps > 0 && n_steps <= 1024, "cfm_inference: bad argument");
+  GSV_REQUIRE(Tp >= 0 && Tp <= T && (Tp == 0 || prompt), "cfm_inference: prompt length %d does not fit %d frames", Tp, T);
+  hipStream_t s = (hipStream_t)stream;
+  const auto& g = c->cfg;
+  float* mods = nullptr;
+  if (c->ctx.dtype == GSV_F16) GSV_RC(cfm_modulations<_Float16>(c, s, n_steps, &mods));
+  else GSV_RC(cfm_modulations<float>(c, s, n_steps, &mods));
+  for (int b = 0; b < B; ++b) {
+    const float* mu_b = mu + (size_t)b * T * g.text_dim;
+    const float* pr_b = prompt ? prompt + (size_t)b * g.mel_dim * Tp : nullptr;
+    const float* nz_b = noise ? noise + (size_t)b * g.mel_dim * T : nullptr;
+    float* out_b = out + (size_t)b * g.mel_dim * T;
+    const unsigned long long sd = (unsigned long long)seed + 0x9E3779B97F4A7C15ull * (unsigned long long)b;
+    if (c->ctx.dtype == GSV_F16) GSV_RC(cfm_infer_one<_Float16>(c, s, mods, mu_b, pr_b, T, Tp, n_steps, nz_b, temperature, sd, out_b));
+    else GSV_RC(cfm_infer_one<float>(c, s, mods, mu_b, pr_b, T, Tp, n_steps, nz_b, temperature, sd, out_b));
+  }
+  return GSV_OK;
+}
+
+}  // extern "C"

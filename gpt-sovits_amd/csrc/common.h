@@ -67,12 +67,27 @@ static inline size_t dt_size(int dt) { return dt == GSV_F16 ? 2 : 4; }
 // ------------------------------------------------------------------------------------
 // generic channels-last implicit-GEMM conv (conv_gemm.hip)
 // ------------------------------------------------------------------------------------
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3, ACT_MISH = 4, ACT_CLAMP1 = 5 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3, ACT_MISH = 4, ACT_CLAMP1 = 5, ACT_SILU = 6, ACT_GELU = 7,
+       ACT_GELU_TANH = 8 };
+
+__device__ __forceinline__ float post_act_f(int act, float u) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(u, 0.f);
+    case ACT_TANH: return tanhf(u);
+    case ACT_MISH: return u * tanhf(u > 20.f ? u : log1pf(expf(u)));   // x * tanh(softplus(x))
+    case ACT_CLAMP1: return fminf(fmaxf(u, -1.f), 1.f);
+    case ACT_SILU: return u / (1.f + expf(-u));
+    case ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+    case ACT_GELU_TANH: return 0.5f * u * (1.f + tanhf(0.79788456080286536f * (u + 0.044715f * u * u * u)));
+    default: return u;
+  }
+}
 
 struct ConvArgs {
   const void* x = nullptr;   // [Z][T_in][ldx] activations, channels-last
   const void* w = nullptr;   // [Z][Cout][ldw]  weights, K index = tap*Cin + cin (cin fastest)
   const float* bias = nullptr;  // [Cout_real] fp32 or null
+  const float* gate = nullptr;  // [Cout_real] fp32 or null: v = ((acc + bias) * gate + res) * scale
   void* y = nullptr;         // [Z][T_out][ldy]
   const void* res = nullptr; // residual, same dtype/shape convention as y (ldr)
   int T_in = 0, T_out = 0;   // valid input rows / output rows actually stored
@@ -91,6 +106,7 @@ struct ConvArgs {
   int ups_u = 0, ups_pad = 0, ups_cout = 0;  // transposed-conv scatter: row = s*u + n/ups_cout - pad
   int Z = 1;
   long long xz = 0, wz = 0, yz = 0, rz = 0;  // batch strides in elements
+  int bz = 0;                                // batch stride of bias / gate (grouped convs)
 };
 int launch_conv_gemm(int dtype, const ConvArgs& a, hipStream_t s);
 // LDS-staged variant for stride-1 convs (conv_lds.hip): 0 = launched, 1 = not eligible, <0 = error

@@ -148,13 +148,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(ConvArgs a) {
         for (int j = 0; j < 4; ++j) {
           if (j >= nvalid) break;
           float u = v[j];
-          if (a.bias) u += a.bias[oc + j];
+          if (a.bias) u += a.bias[z * a.bz + oc + j];
+          if (a.gate) u *= a.gate[z * a.bz + oc + j];
           if (a.res) u += a.res_f32 ? ((const float*)a.res)[roff + j] : to_f(((const T*)a.res)[roff + j]);
           u *= a.scale;
-          if (a.post_act == ACT_RELU) u = fmaxf(u, 0.f);
-          else if (a.post_act == ACT_TANH) u = tanhf(u);
-          else if (a.post_act == ACT_MISH) u = u * tanhf(u > 20.f ? u : log1pf(expf(u)));
-        else if (a.post_act == ACT_CLAMP1) u = fminf(fmaxf(u, -1.f), 1.f);  // x*tanh(softplus(x))
+          u = post_act_f(a.post_act, u);
           if (a.accumulate) u += a.out_f32 ? ((float*)a.y)[yoff + j] : to_f(((T*)a.y)[yoff + j]);
           v[j] = u;
         }

@@ -88,6 +88,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
   const int env = max(0, min(4, a.Cout - ec));
   f4 ebias = (f4){0.f, 0.f, 0.f, 0.f};
   if (a.bias) for (int j = 0; j < env; ++j) ebias[j] = a.bias[eoc + j];
+  f4 egate = (f4){1.f, 1.f, 1.f, 1.f};
+  if (a.gate) for (int j = 0; j < env; ++j) egate[j] = a.gate[eoc + j];
   // the wide tile (CT = 128) keeps only the residual in registers; its accumulate operand is fetched per
   // pass (that tile has ~19 us of MFMA work, the narrow ones have <2 us and must not stall at all)
   constexpr bool PRE_ACC = ACCU && CT < 128;
@@ -273,13 +275,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float u = av[j] + ebias[j];
+        float u = (av[j] + ebias[j]) * egate[j];
         if (RES) u += to_f(rv[q][j]);
         u *= a.scale;
-        if (a.post_act == ACT_RELU) u = fmaxf(u, 0.f);
-        else if (a.post_act == ACT_TANH) u = tanhf(u);
-        else if (a.post_act == ACT_MISH) u = u * tanhf(u > 20.f ? u : log1pf(expf(u)));
-        else if (a.post_act == ACT_CLAMP1) u = fminf(fmaxf(u, -1.f), 1.f);
+        u = post_act_f(a.post_act, u);
         if (PRE_ACC) u += to_f(yv[q][j]);
         else if (ACCU) u += to_f(ya[e][j]);
         v[j] = u;
@@ -335,7 +334,9 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
   const int ecg = tid % IPR, ec = cout0 + 4 * ecg;
   const int env = max(0, min(4, a.Cout - ec));
   f4 ebias = (f4){0.f, 0.f, 0.f, 0.f};
-  if (a.bias) for (int j = 0; j < env; ++j) ebias[j] = a.bias[ec + j];
+  if (a.bias) for (int j = 0; j < env; ++j) ebias[j] = a.bias[z * a.bz + ec + j];
+  f4 egate = (f4){1.f, 1.f, 1.f, 1.f};
+  if (a.gate) for (int j = 0; j < env; ++j) egate[j] = a.gate[z * a.bz + ec + j];
   T4 rv[RES ? WN * NI : 1];
   rv[0] = (T4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
   if (RES) {
@@ -444,13 +445,10 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float u = av[j] + ebias[j];
+        float u = (av[j] + ebias[j]) * egate[j];
         if (RES) u += to_f(rv[q][j]);
         u *= a.scale;
-        if (a.post_act == ACT_RELU) u = fmaxf(u, 0.f);
-        else if (a.post_act == ACT_TANH) u = tanhf(u);
-        else if (a.post_act == ACT_MISH) u = u * tanhf(u > 20.f ? u : log1pf(expf(u)));
-        else if (a.post_act == ACT_CLAMP1) u = fminf(fmaxf(u, -1.f), 1.f);
+        u = post_act_f(a.post_act, u);
         v[j] = u;
       }
       const long long yoff = ybase + (long long)t * a.ldy + a.y_col0 + ec;

@@ -9,12 +9,7 @@
 // terms (cond(ge), WN cond_layer(ge)) folded into biases once per reference audio.
 // A single sequence is decoded per call (as in the reference, TTS.py:1266-1273 folds the
 // batch into the time axis), so all x_mask terms are identically one and are dropped.
-#include <math.h>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "common.h"
+#include "engine.h"
 
 namespace gsv {
 
@@ -335,52 +330,9 @@ using namespace gsv;
 // =======================================================================================
 // engine
 // =======================================================================================
-struct Conv {
-  void* w = nullptr;     // T [cout][taps*cin]
-  float* b = nullptr;    // fp32 [cout_real] or null
-  int cin = 0, cout = 0, taps = 1;
-  int ups_u = 0, ups_pad = 0, ups_cout = 0;
-};
 
-struct AttnLayerW { Conv qkv, o; float *rel_k = nullptr, *rel_v = nullptr; float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr; Conv f1, f2; };
-struct WNW { Conv in[4], res[4], skip[4]; float* in_bias_eff[4] = {nullptr, nullptr, nullptr, nullptr}; Conv cond; };
-struct FlowW { Conv pre, post; WNW wn; };
+namespace gsveng {
 
-struct Buf { void* p = nullptr; size_t cap = 0; };
-
-struct gsv_vits {
-  gsv_vits_config cfg;
-  int dtype;
-  bool finalized = false, has_ref = false;
-  std::map<std::string, std::vector<float>> staged;
-  std::vector<void*> allocs;
-  // weights
-  Conv ssl_proj_enc, proj, c_pre, text_pre, c_post, mq, mkv, mo;
-  std::vector<AttnLayerW> enc_ssl, enc_text, enc2;
-  float *text_emb = nullptr, *codebook = nullptr, *code_ee = nullptr;
-  Conv top_ssl_proj;
-  void* codebook_t = nullptr;
-  FlowW flows[4];
-  Conv conv_pre, conv_post, cond;
-  float* conv_pre_bias_eff = nullptr;
-  std::vector<Conv> ups;
-  std::vector<Conv> rb1, rb2;  // [stage][j][c]
-  // ref_enc
-  Conv r_sp0, r_sp3, r_t0, r_t1, r_qkv, r_fc, r_out;
-  float* ge = nullptr;         // fp32 [gin]
-  void* ge_t = nullptr;        // T [gin]
-  float* mo_bias_eff = nullptr;
-  // workspace
-  std::map<std::string, Buf> bufs;
-  // last decode bookkeeping
-  int lastF = 0;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  float last_total_ms = 0.f, last_gen_ms = 0.f;
-};
-
-namespace {
-
-size_t esz(const gsv_vits* h) { return dt_size(h->dtype); }
 
 int dalloc(gsv_vits* h, void** p, size_t bytes) {
   GSV_HIP(hipMalloc(p, bytes ? bytes : 16));
@@ -527,15 +479,6 @@ int need(gsv_vits* h, const char* name, size_t bytes, void** out) {
   return GSV_OK;
 }
 
-struct ConvOpt {
-  int dil = 1, pad = -1, stride = 1;
-  int pre_act = ACT_NONE; float pre_slope = 0.1f;
-  int post_act = ACT_NONE; float scale = 1.f; int accumulate = 0;
-  int out_f32 = 0; const void* res = nullptr; int res_f32 = 0; int ldr = 0;
-  int ldy = 0, y_col0 = 0;
-  const float* bias_override = nullptr; bool no_bias = false;
-  int w_row0 = 0, cout = -1;   // use a row slice of the weight matrix
-};
 
 int conv(gsv_vits* h, hipStream_t s, const Conv& c, const void* x, int ldx, int T_in, void* y, int T_out, const ConvOpt& o) {
   ConvArgs a;
@@ -543,6 +486,7 @@ int conv(gsv_vits* h, hipStream_t s, const Conv& c, const void* x, int ldx, int 
   const int cout = o.cout >= 0 ? o.cout : c.cout;
   a.w = (const char*)c.w + (size_t)o.w_row0 * c.taps * c.cin * esz(h);
   a.bias = o.no_bias ? nullptr : (o.bias_override ? o.bias_override : (c.b ? c.b + (c.ups_u ? 0 : o.w_row0) : nullptr));
+  a.gate = o.gate;
   a.T_in = T_in; a.T_out = T_out; a.Cin = c.cin; a.Cout = cout; a.taps = c.taps;
   a.stride = o.stride; a.dil = o.dil;
   a.pad = o.pad >= 0 ? o.pad : (c.taps * o.dil - o.dil) / 2;
@@ -563,10 +507,6 @@ int conv(gsv_vits* h, hipStream_t s, const Conv& c, const void* x, int ldx, int 
   return launch_conv_gemm(h->dtype, a, s);
 }
 
-#define GSV_DISPATCH(h, call_f16, call_f32) \
-  do { if ((h)->dtype == GSV_F16) { call_f16; } else { call_f32; } } while (0)
-
-inline int nblk(long long n, int b = 256) { return (int)((n + b - 1) / b); }
 
 // materialised multi-head attention: q [Tq][ldq] cols qcol0.., k/v [Tk][ldkv] cols kcol0/vcol0..
 // -> out [Tq][ldo] (heads concatenated).  rel_k/rel_v non-null: window-4 relative positions.
@@ -636,7 +576,15 @@ int run_encoder(gsv_vits* h, hipStream_t s, std::vector<AttnLayerW>& layers, voi
   return GSV_OK;
 }
 
-}  // namespace
+void free_ctx(gsv_vits* h) {
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (auto& b : h->bufs) if (b.second.p) (void)hipFree(b.second.p);
+  h->allocs.clear();
+  h->bufs.clear();
+}
+
+}  // namespace gsveng
+using namespace gsveng;
 
 extern "C" {
 
@@ -1060,7 +1008,7 @@ struct gsv_vocoder {
   bool finalized = false;
 };
 
-namespace {
+namespace gsveng {
 
 // Conv1d weight [cout][cin][k] with the input channels zero-padded to cin_pad
 int make_conv_padded(gsv_vits* h, const std::string& name, int cout, int cin, int cin_pad, int k, bool bias, Conv* c) {
@@ -1111,7 +1059,7 @@ int voc_act(gsv_vocoder* v, hipStream_t s, const VocAct& a, const void* x, void*
   return GSV_OK;
 }
 
-}  // namespace
+}  // namespace gsveng
 
 extern "C" {
 

@@ -36,6 +36,10 @@ class VocoderConfig(C.Structure):
                 ("tanh_at_final", C.c_int), ("snake_logscale", C.c_int)]
 
 
+class DitConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("dim", "depth", "heads", "dim_head", "ff_mult", "mel_dim", "text_dim", "conv_layers")]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("res", C.c_void_p),
                 ("T_in", C.c_int), ("T_out", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("taps", C.c_int),
@@ -79,6 +83,12 @@ _SIGS = {
     "gsv_vocoder_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     "gsv_vocoder_finalize": (C.c_int, [C.c_void_p]),
     "gsv_vocoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gsv_cfm_create": (C.c_int, [C.POINTER(DitConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    "gsv_cfm_destroy": (None, [C.c_void_p]),
+    "gsv_cfm_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "gsv_cfm_finalize": (C.c_int, [C.c_void_p]),
+    "gsv_cfm_inference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
     "gsv_aa_act_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gsv_op_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),

@@ -202,3 +202,47 @@ class Generator:
         if g is not None:
             raise NotImplementedError("conditioning input g")
         return self._e(x)
+
+
+class CFM:
+    """Mirror of the reference's `CFM` (module/models.py:1013-1085): `inference` integrates the flow-matching ODE with
+    `n_timesteps` Euler steps over the `DiT` estimator, entirely inside the HIP library (`gsv_cfm_inference`).
+
+    `noise` (not in the reference signature) pins the `torch.randn` draw of models.py:1030 for parity tests; left
+    None, the draw happens on the device from `seed`.
+    """
+
+    def __init__(self, in_channels, dit):
+        self.in_channels = in_channels
+        self.estimator = dit
+        self.sigma_min = 1e-6
+
+    @torch.no_grad()
+    def inference(self, mu, x_lens, prompt, n_timesteps, temperature=1.0, inference_cfg_rate=0, noise=None, seed=0):
+        """mu [B, T, text_dim]; x_lens unused (as in the reference); prompt [B, in_channels, Tp] -> [B, in_channels, T]"""
+        if inference_cfg_rate > 1e-5:
+            raise NotImplementedError("classifier-free guidance: every caller in the reference passes inference_cfg_rate=0 "
+                                      "(TTS.py:1351, inference_webui.py:937)")
+        dit = self.estimator
+        if not dit._loaded:
+            raise RuntimeError("DiT.load_state_dict() first")
+        if mu.dim() != 3 or mu.shape[2] != dit.text_dim or mu.shape[1] < 1:
+            raise ValueError(f"expected mu of shape [B, T>=1, {dit.text_dim}], got {tuple(mu.shape)}")
+        B, T = int(mu.shape[0]), int(mu.shape[1])
+        if prompt.dim() != 3 or prompt.shape[0] != B or prompt.shape[1] != self.in_channels or prompt.shape[2] > T:
+            raise ValueError(f"expected prompt of shape [{B}, {self.in_channels}, Tp<={T}], got {tuple(prompt.shape)}")
+        Tp = int(prompt.shape[2])
+        if noise is not None and tuple(noise.shape) != (B, self.in_channels, T):
+            raise ValueError(f"noise must have shape {(B, self.in_channels, T)}")
+        dev = dit.device
+        with torch.cuda.device(dev):
+            dit.stream.wait_stream(torch.cuda.current_stream(dev))
+            m = mu.to(dev, torch.float32).contiguous()
+            p = prompt.to(dev, torch.float32).contiguous()
+            nz = noise.to(dev, torch.float32).contiguous() if noise is not None else None
+            out = torch.empty(B, self.in_channels, T, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().gsv_cfm_inference(dit._h, m.data_ptr(), p.data_ptr() if Tp else None, B, T, Tp, int(n_timesteps),
+                                                    nz.data_ptr() if nz is not None else None, float(temperature), int(seed),
+                                                    out.data_ptr(), C.c_void_p(dit.stream.cuda_stream)), "gsv_cfm_inference")
+            dit.stream.synchronize()
+        return out.to(mu.dtype if mu.dtype in (torch.float16, torch.float32) else torch.float32)

@@ -173,6 +173,30 @@ int gsv_vocoder_finalize(gsv_vocoder_t* h);
 int gsv_vocoder_forward(gsv_vocoder_t* h, const float* mel, int F, float* wav, gsv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * v3 / v4 flow-matching mel decoder (H14): CFM.inference (module/models.py:1027-1085, inference_cfg_rate = 0 as
+ * every caller in the reference passes it) over the DiT estimator (f5_tts/model/backbones/dit.py:88-194).
+ * Tensor names = the DiT state-dict keys (the part after "cfm.estimator." in a v3/v4 SoVITS checkpoint).
+ * The rotary embedding follows x_transformers' published definition (un-vendored dependency: parity unpinned).
+ * ------------------------------------------------------------------------------------- */
+typedef struct gsv_cfm gsv_cfm_t;
+
+typedef struct {
+  int dim, depth, heads, dim_head, ff_mult;   /* 1024, 22, 16, 64, 2 (module/models.py:1219-1222) */
+  int mel_dim, text_dim, conv_layers;         /* 100, 512, 4 */
+} gsv_dit_config;
+
+int gsv_cfm_create(const gsv_dit_config* cfg, int dtype, gsv_cfm_t** out);
+void gsv_cfm_destroy(gsv_cfm_t* h);
+int gsv_cfm_load_tensor(gsv_cfm_t* h, const char* name, const float* data, int64_t numel);
+int gsv_cfm_finalize(gsv_cfm_t* h);
+/* mu [dev] fp32 [B][T][text_dim] (the `fea` tensor as CFM.inference receives it), prompt [dev] fp32 [B][mel_dim][Tp]
+ * (the reference mel, frames >= Tp are generated), noise [dev] fp32 [B][mel_dim][T] = the randn draw of models.py:1030,
+ * or NULL to draw it on the device from `seed`; out [dev] fp32 [B][mel_dim][T] (prompt frames are zero, as in the
+ * reference).  n_steps Euler steps with d = 1/n_steps. */
+int gsv_cfm_inference(gsv_cfm_t* h, const float* mu, const float* prompt, int B, int T, int Tp, int n_steps,
+                      const float* noise, float temperature, uint64_t seed, float* out, gsv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * BigVGAN anti-aliased snake activation (v3 vocoder), the reference's one native kernel.
  * x,y [dev] [B][C][T] of `dtype`; up12/dn12 [dev] 12 filter taps; log_alpha/log_beta [dev] [C].
  * T == 0 returns GSV_OK without a launch (anti_alias_activation_cuda.cu:193-196).
