@@ -38,6 +38,10 @@ struct gsv_vits {
   float* conv_pre_bias_eff = nullptr;
   std::vector<Conv> ups;
   std::vector<Conv> rb1, rb2;  // [stage][j][c]
+  // v3 / v4: bridge + wns1 (Encoder with an 8-layer WN)
+  Conv bridge, w1_pre, w1_proj, w1_cond;
+  std::vector<Conv> w1_in, w1_res;
+  std::vector<float*> w1_in_bias_eff;
   // ref_enc
   Conv r_sp0, r_sp3, r_t0, r_t1, r_qkv, r_fc, r_out;
   float* ge = nullptr;         // fp32 [gin]

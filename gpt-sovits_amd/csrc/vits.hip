@@ -299,6 +299,14 @@ __global__ void interp_linear_kernel(const T* __restrict__ x, int Tin, int Tout,
     y[(long long)t * C + c] = (T)(w0 * to_f(x[(long long)i0 * C + c]) + w1 * to_f(x[(long long)i1 * C + c]));
 }
 
+// F.interpolate(mode="nearest", scale_factor=sf) along time: src = min(floor(dst * (float)(1/sf)), Tin - 1)
+template <typename T>
+__global__ void interp_nearest_kernel(const T* __restrict__ x, int Tin, int Tout, int C, float scale, T* __restrict__ y) {
+  const int t = blockIdx.x;
+  const int src = min((int)floorf((float)t * scale), Tin - 1);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) y[(long long)t * C + c] = x[(long long)src * C + c];
+}
+
 __global__ void vec_add_kernel(const float* a, const float* b, float* out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] + b[i];
@@ -586,12 +594,73 @@ void free_ctx(gsv_vits* h) {
 }  // namespace gsveng
 using namespace gsveng;
 
+namespace gsveng {
+
+// quantizer.decode + nearest x2 (H8) and TextEncoder.forward up to (and including) the speed interpolation (H10, reference
+// module/models.py:199-231): returns the hidden sequence y [F][hidden] (what `enc_p` returns as its first value)
+int run_enc_p(gsv_vits* h, hipStream_t s, const int32_t* codes, int T, const int32_t* phones, int L, double speed, void** y_out,
+              int* F_out) {
+  const auto& c = h->cfg;
+  const size_t es = esz(h);
+  const int H = c.hidden_channels, SSL = c.ssl_dim, MH = 512;
+  const int F0 = 2 * T;
+  const int F = (speed == 1.0) ? F0 : (int)((double)F0 / speed) + 1;   // frames after the speed interpolation
+  // ---- H8: codebook gather + nearest x2
+  void *q768, *y, *tx;
+  GSV_RC(need(h, "q768", (size_t)F0 * SSL * es, &q768));
+  GSV_RC(need(h, "enc_x", (size_t)F0 * H * es, &y));
+  GSV_RC(need(h, "enc_tx", (size_t)L * H * es, &tx));
+  GSV_DISPATCH(h,
+    hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(F0), dim3(128), 0, s, codes, h->codebook, SSL, 2, T, (_Float16*)q768),
+    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(F0), dim3(128), 0, s, codes, h->codebook, SSL, 2, T, (float*)q768));
+  // ---- H10: enc_p
+  ConvOpt o;
+  GSV_RC(conv(h, s, h->ssl_proj_enc, q768, SSL, F0, y, F0, o));
+  GSV_RC(run_encoder(h, s, h->enc_ssl, y, F0));
+  GSV_DISPATCH(h,
+    hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(L), dim3(128), 0, s, phones, h->text_emb, H, 1, L, (_Float16*)tx),
+    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(L), dim3(128), 0, s, phones, h->text_emb, H, 1, L, (float*)tx));
+  GSV_RC(run_encoder(h, s, h->enc_text, tx, L));
+  {  // MRTE (mrte_model.py:25-44)
+    void *s512, *t512, *q512, *kv512, *o512, *x512;
+    GSV_RC(need(h, "m_s", (size_t)F0 * MH * es, &s512));
+    GSV_RC(need(h, "m_t", (size_t)L * MH * es, &t512));
+    GSV_RC(need(h, "m_q", (size_t)F0 * MH * es, &q512));
+    GSV_RC(need(h, "m_kv", (size_t)L * 2 * MH * es, &kv512));
+    GSV_RC(need(h, "m_o", (size_t)F0 * MH * es, &o512));
+    GSV_RC(need(h, "m_x", (size_t)F0 * MH * es, &x512));
+    GSV_RC(conv(h, s, h->c_pre, y, H, F0, s512, F0, o));
+    GSV_RC(conv(h, s, h->text_pre, tx, H, L, t512, L, o));
+    GSV_RC(conv(h, s, h->mq, s512, MH, F0, q512, F0, o));
+    GSV_RC(conv(h, s, h->mkv, t512, MH, L, kv512, L, o));
+    GSV_RC(attention(h, s, q512, MH, 0, kv512, 2 * MH, 0, MH, F0, L, 4, MH / 4, 1.f / sqrtf((float)(MH / 4)), nullptr, nullptr, o512, MH));
+    ConvOpt om; om.res = s512; om.ldr = MH; om.bias_override = h->mo_bias_eff;
+    GSV_RC(conv(h, s, h->mo, o512, MH, F0, x512, F0, om));
+    GSV_RC(conv(h, s, h->c_post, x512, MH, F0, y, F0, o));
+  }
+  GSV_RC(run_encoder(h, s, h->enc2, y, F0));
+  if (F != F0) {
+    void* yi;
+    GSV_RC(need(h, "enc_x_speed", (size_t)F * H * es, &yi));
+    GSV_DISPATCH(h,
+      hipLaunchKernelGGL(interp_linear_kernel<_Float16>, dim3(F), dim3(64), 0, s, (const _Float16*)y, F0, F, H, (_Float16*)yi),
+      hipLaunchKernelGGL(interp_linear_kernel<float>, dim3(F), dim3(64), 0, s, (const float*)y, F0, F, H, (float*)yi));
+    y = yi;
+  }
+  *y_out = y;
+  *F_out = F;
+  return GSV_OK;
+}
+
+}  // namespace gsveng
+
 extern "C" {
 
 int gsv_vits_create(const gsv_vits_config* cfg, int dtype, gsv_vits_t** out) {
   GSV_REQUIRE(cfg && out, "vits_create: null argument");
   GSV_REQUIRE(dtype == GSV_F16 || dtype == GSV_F32, "vits_create: bad dtype");
-  GSV_REQUIRE(cfg->n_ups >= 1 && cfg->n_ups <= 8 && cfg->n_resblocks >= 1 && cfg->n_resblocks <= 4, "vits_create: bad generator shape");
+  GSV_REQUIRE(cfg->flavor >= 0 && cfg->flavor <= 2, "vits_create: flavor must be 0 (v1/v2), 1 (v3) or 2 (v4)");
+  GSV_REQUIRE(cfg->flavor != 0 || (cfg->n_ups >= 1 && cfg->n_ups <= 8 && cfg->n_resblocks >= 1 && cfg->n_resblocks <= 4), "vits_create: bad generator shape");
   GSV_REQUIRE(cfg->hidden_channels % cfg->n_heads == 0 && (cfg->hidden_channels / cfg->n_heads) % 8 == 0, "vits_create: head dim must be a multiple of 8");
   GSV_REQUIRE(cfg->inter_channels % 16 == 0, "vits_create: inter_channels must be a multiple of 16");
   int n = 0;
@@ -652,6 +721,7 @@ int gsv_vits_finalize(gsv_vits_t* h) {
     GSV_RC(up_f32(h, ee.data(), ee.size(), &h->code_ee));
     GSV_RC(make_conv(h, "ssl_proj", SSL, SSL, 2, true, &h->top_ssl_proj));
   }
+  if (c.flavor == 0) {
   // flow
   for (int fi = 0; fi < 4; ++fi) {
     FlowW& f = h->flows[fi];
@@ -690,6 +760,21 @@ int gsv_vits_finalize(gsv_vits_t* h) {
     }
   }
   GSV_RC(make_conv(h, "dec.conv_post", 1, ch, 7, false, &h->conv_post));
+  } else {
+    // v3 / v4 (SynthesizerTrnV3, module/models.py:1203-1206): bridge + wns1 = Encoder(512, 512, 512, 5, 1, 8, gin)
+    const int W = 512, NL = 8;
+    GSV_REQUIRE(IC == H, "vits: v3/v4 need inter_channels == hidden_channels (bridge = Conv1d(inter, 512) on the hidden sequence)");
+    GSV_RC(make_conv(h, "bridge.0", W, IC, 1, true, &h->bridge));
+    GSV_RC(make_conv(h, "wns1.pre", W, W, 1, true, &h->w1_pre));
+    GSV_RC(make_conv(h, "wns1.proj", W, W, 1, true, &h->w1_proj));
+    GSV_RC(make_conv(h, "wns1.enc.cond_layer", 2 * W * NL, GIN, 1, true, &h->w1_cond));
+    h->w1_in.resize(NL); h->w1_res.resize(NL); h->w1_in_bias_eff.resize(NL);
+    for (int li = 0; li < NL; ++li) {
+      GSV_RC(make_conv(h, "wns1.enc.in_layers." + std::to_string(li), 2 * W, W, 5, true, &h->w1_in[li]));
+      GSV_RC(make_conv(h, "wns1.enc.res_skip_layers." + std::to_string(li), li < NL - 1 ? 2 * W : W, W, 1, true, &h->w1_res[li]));
+      GSV_RC(dalloc(h, (void**)&h->w1_in_bias_eff[li], (size_t)2 * W * 4));
+    }
+  }
   // ref_enc
   const int RH = 128;
   GSV_RC(make_conv(h, "ref_enc.spectral.0.fc", RH, c.ref_bins, 1, true, &h->r_sp0));
@@ -755,15 +840,22 @@ int gsv_vits_set_refer(gsv_vits_t* h, const float* const* specs, const int* fram
   GSV_RC(need(h, "cond_tmp", (size_t)2048 * 4 * 4, (void**)&tmp));
   {
     ConvOpt o; o.out_f32 = 1;
+    hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(GIN, 256)), dim3(256), 0, s, h->ge, h->mo.b, h->mo_bias_eff, GIN);
+    if (c.flavor != 0) {
+      GSV_RC(conv(h, s, h->w1_cond, h->ge_t, GIN, 1, tmp, 1, o));
+      const int n = 2 * 512;
+      for (size_t li = 0; li < h->w1_in.size(); ++li)
+        hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, tmp + li * n, h->w1_in[li].b, h->w1_in_bias_eff[li], n);
+    } else {
     GSV_RC(conv(h, s, h->cond, h->ge_t, GIN, 1, tmp, 1, o));
     hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(h->conv_pre.cout, 256)), dim3(256), 0, s, tmp, h->conv_pre.b, h->conv_pre_bias_eff, h->conv_pre.cout);
-    hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(GIN, 256)), dim3(256), 0, s, h->ge, h->mo.b, h->mo_bias_eff, GIN);
     for (int fi = 0; fi < 4; ++fi) {
       WNW& w = h->flows[fi].wn;
       GSV_RC(conv(h, s, w.cond, h->ge_t, GIN, 1, tmp, 1, o));
       const int n = 2 * c.hidden_channels;
       for (int li = 0; li < 4; ++li)
         hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, tmp + li * n, w.in[li].b, w.in_bias_eff[li], n);
+    }
     }
   }
   GSV_HIP(hipGetLastError());
@@ -772,60 +864,21 @@ int gsv_vits_set_refer(gsv_vits_t* h, const float* const* specs, const int* fram
 }
 
 int gsv_vits_decode(gsv_vits_t* h, const int32_t* codes, int T, const int32_t* phones, int L, const float* noise,
-                    float noise_scale, float speed, uint64_t seed, float* wav, gsv_stream_t stream) {
+                    float noise_scale, double speed, uint64_t seed, float* wav, gsv_stream_t stream) {
   GSV_REQUIRE(h && h->finalized, "vits_decode: handle not finalized");
   GSV_REQUIRE(h->has_ref, "vits_decode: call gsv_vits_set_refer first");
   GSV_REQUIRE(codes && phones && wav && T >= 1 && L >= 1, "vits_decode: empty input (T=%d, L=%d)", T, L);
   hipStream_t s = (hipStream_t)stream;
   const auto& c = h->cfg;
   const size_t es = esz(h);
-  const int H = c.hidden_channels, IC = c.inter_channels, SSL = c.ssl_dim, MH = 512;
-  const int F0 = 2 * T;
-  GSV_REQUIRE(speed > 0.f, "vits_decode: speed must be positive");
-  const int F = (speed == 1.f) ? F0 : (int)((float)F0 / speed) + 1;   // frames after the speed interpolation
+  const int H = c.hidden_channels, IC = c.inter_channels;
+  GSV_REQUIRE(speed > 0.0, "vits_decode: speed must be positive");
+  GSV_REQUIRE(c.flavor == 0, "vits_decode: this handle is a v3/v4 model (use gsv_vits_decode_encp + gsv_cfm_inference + a vocoder)");
   GSV_HIP(hipEventRecord(h->ev[0], s));
-  // ---- H8: codebook gather + nearest x2
-  void *q768, *y, *tx;
-  GSV_RC(need(h, "q768", (size_t)F0 * SSL * es, &q768));
-  GSV_RC(need(h, "enc_x", (size_t)F0 * H * es, &y));
-  GSV_RC(need(h, "enc_tx", (size_t)L * H * es, &tx));
-  GSV_DISPATCH(h,
-    hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(F0), dim3(128), 0, s, codes, h->codebook, SSL, 2, T, (_Float16*)q768),
-    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(F0), dim3(128), 0, s, codes, h->codebook, SSL, 2, T, (float*)q768));
-  // ---- H10: enc_p
+  void* y = nullptr;
+  int F = 0;
+  GSV_RC(run_enc_p(h, s, codes, T, phones, L, speed, &y, &F));
   ConvOpt o;
-  GSV_RC(conv(h, s, h->ssl_proj_enc, q768, SSL, F0, y, F0, o));
-  GSV_RC(run_encoder(h, s, h->enc_ssl, y, F0));
-  GSV_DISPATCH(h,
-    hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(L), dim3(128), 0, s, phones, h->text_emb, H, 1, L, (_Float16*)tx),
-    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(L), dim3(128), 0, s, phones, h->text_emb, H, 1, L, (float*)tx));
-  GSV_RC(run_encoder(h, s, h->enc_text, tx, L));
-  {  // MRTE (mrte_model.py:25-44)
-    void *s512, *t512, *q512, *kv512, *o512, *x512;
-    GSV_RC(need(h, "m_s", (size_t)F0 * MH * es, &s512));
-    GSV_RC(need(h, "m_t", (size_t)L * MH * es, &t512));
-    GSV_RC(need(h, "m_q", (size_t)F0 * MH * es, &q512));
-    GSV_RC(need(h, "m_kv", (size_t)L * 2 * MH * es, &kv512));
-    GSV_RC(need(h, "m_o", (size_t)F0 * MH * es, &o512));
-    GSV_RC(need(h, "m_x", (size_t)F0 * MH * es, &x512));
-    GSV_RC(conv(h, s, h->c_pre, y, H, F0, s512, F0, o));
-    GSV_RC(conv(h, s, h->text_pre, tx, H, L, t512, L, o));
-    GSV_RC(conv(h, s, h->mq, s512, MH, F0, q512, F0, o));
-    GSV_RC(conv(h, s, h->mkv, t512, MH, L, kv512, L, o));
-    GSV_RC(attention(h, s, q512, MH, 0, kv512, 2 * MH, 0, MH, F0, L, 4, MH / 4, 1.f / sqrtf((float)(MH / 4)), nullptr, nullptr, o512, MH));
-    ConvOpt om; om.res = s512; om.ldr = MH; om.bias_override = h->mo_bias_eff;
-    GSV_RC(conv(h, s, h->mo, o512, MH, F0, x512, F0, om));
-    GSV_RC(conv(h, s, h->c_post, x512, MH, F0, y, F0, o));
-  }
-  GSV_RC(run_encoder(h, s, h->enc2, y, F0));
-  if (F != F0) {
-    void* yi;
-    GSV_RC(need(h, "enc_x_speed", (size_t)F * H * es, &yi));
-    GSV_DISPATCH(h,
-      hipLaunchKernelGGL(interp_linear_kernel<_Float16>, dim3(F), dim3(64), 0, s, (const _Float16*)y, F0, F, H, (_Float16*)yi),
-      hipLaunchKernelGGL(interp_linear_kernel<float>, dim3(F), dim3(64), 0, s, (const float*)y, F0, F, H, (float*)yi));
-    y = yi;
-  }
   float* stats;
   GSV_RC(need(h, "stats", (size_t)F * 2 * IC * 4, (void**)&stats));
   { ConvOpt of; of.out_f32 = 1; GSV_RC(conv(h, s, h->proj, y, H, F, stats, F, of)); }
@@ -914,6 +967,80 @@ int gsv_vits_decode(gsv_vits_t* h, const int32_t* codes, int T, const int32_t* p
   { ConvOpt op; op.pre_act = ACT_LRELU; op.pre_slope = 0.01f; op.post_act = ACT_TANH; op.out_f32 = 1;
     GSV_RC(conv(h, s, h->conv_post, cur, ch, Tn, wav, Tn, op)); }
   GSV_HIP(hipEventRecord(h->ev[2], s));
+  return GSV_OK;
+}
+
+int gsv_vits_encp_frames(gsv_vits_t* h, int T, double speed) {
+  if (!h || T < 1 || !(speed > 0.0)) return -1;
+  const int F0 = 2 * T;
+  const int Fs = (speed == 1.0) ? F0 : (int)((double)F0 / speed) + 1;
+  const double sf = h->cfg.flavor == 1 ? 1.875 : 2.0;
+  return (int)floor((double)Fs * sf);
+}
+
+int gsv_vits_decode_encp(gsv_vits_t* h, const int32_t* codes, int T, const int32_t* phones, int L, double speed, float* fea,
+                         gsv_stream_t stream) {
+  GSV_REQUIRE(h && h->finalized, "vits_decode_encp: handle not finalized");
+  GSV_REQUIRE(h->cfg.flavor != 0, "vits_decode_encp: this handle is a v1/v2 model (use gsv_vits_decode)");
+  GSV_REQUIRE(h->has_ref, "vits_decode_encp: call gsv_vits_set_refer first");
+  GSV_REQUIRE(codes && phones && fea && T >= 1 && L >= 1, "vits_decode_encp: empty input (T=%d, L=%d)", T, L);
+  GSV_REQUIRE(speed > 0.0, "vits_decode_encp: speed must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  const auto& c = h->cfg;
+  const size_t es = esz(h);
+  const int H = c.hidden_channels, W = 512, NL = (int)h->w1_in.size();
+  void* y = nullptr;
+  int Fs = 0;
+  GSV_RC(run_enc_p(h, s, codes, T, phones, L, speed, &y, &Fs));
+  const double sf = c.flavor == 1 ? 1.875 : 2.0;
+  const int F = (int)floor((double)Fs * sf);
+  // wns1's mask length (models.py:1252-1258): frames >= Lm are zeroed at every masked point of Encoder / WN
+  const double per = c.flavor == 1 ? 3.875 : 4.0;
+  const int sizee = (speed == 1.0) ? (int)((double)T * per) : (int)((double)T * per / speed) + 1;
+  const int Lm = std::min(sizee, F);
+  void *br, *up, *hb, *xin, *acts, *wout, *st;
+  GSV_RC(need(h, "e_br", (size_t)Fs * W * es, &br));
+  GSV_RC(need(h, "e_up", (size_t)F * W * es, &up));
+  GSV_RC(need(h, "e_h", (size_t)F * W * es, &hb));
+  GSV_RC(need(h, "e_xin", (size_t)F * 2 * W * es, &xin));
+  GSV_RC(need(h, "e_acts", (size_t)F * W * es, &acts));
+  GSV_RC(need(h, "e_out", (size_t)F * W * es, &wout));
+  GSV_RC(need(h, "e_st", (size_t)F * W * es, &st));
+  auto mask_tail = [&](void* p) -> int {
+    if (Lm < F) GSV_HIP(hipMemsetAsync((char*)p + (size_t)Lm * W * es, 0, (size_t)(F - Lm) * W * es, s));
+    return GSV_OK;
+  };
+  { ConvOpt ob; ob.post_act = ACT_LRELU01; GSV_RC(conv(h, s, h->bridge, y, H, Fs, br, Fs, ob)); }   // bridge: 1x1 + LeakyReLU(0.01)
+  GSV_DISPATCH(h,
+    hipLaunchKernelGGL(interp_nearest_kernel<_Float16>, dim3(F), dim3(128), 0, s, (const _Float16*)br, Fs, F, W, (float)(1.0 / sf), (_Float16*)up),
+    hipLaunchKernelGGL(interp_nearest_kernel<float>, dim3(F), dim3(128), 0, s, (const float*)br, Fs, F, W, (float)(1.0 / sf), (float*)up));
+  ConvOpt o;
+  GSV_RC(conv(h, s, h->w1_pre, up, W, F, hb, F, o));
+  GSV_RC(mask_tail(hb));
+  for (int li = 0; li < NL; ++li) {                        // modules.WN.forward (modules.py:  in -> gate -> res/skip)
+    ConvOpt oi; oi.bias_override = h->w1_in_bias_eff[li];
+    GSV_RC(conv(h, s, h->w1_in[li], hb, W, F, xin, F, oi));
+    GSV_DISPATCH(h,
+      hipLaunchKernelGGL(gate_kernel<_Float16>, dim3(nblk((long long)F * W)), dim3(256), 0, s, (const _Float16*)xin, (long long)F * W, W, (_Float16*)acts),
+      hipLaunchKernelGGL(gate_kernel<float>, dim3(nblk((long long)F * W)), dim3(256), 0, s, (const float*)xin, (long long)F * W, W, (float*)acts));
+    if (li < NL - 1) {
+      ConvOpt ores; ores.cout = W; ores.w_row0 = 0; ores.accumulate = 1;
+      GSV_RC(conv(h, s, h->w1_res[li], acts, W, F, hb, F, ores));
+      GSV_RC(mask_tail(hb));
+      ConvOpt osk; osk.cout = W; osk.w_row0 = W; osk.accumulate = li > 0;
+      GSV_RC(conv(h, s, h->w1_res[li], acts, W, F, wout, F, osk));
+    } else {
+      ConvOpt osk; osk.accumulate = NL > 1;
+      GSV_RC(conv(h, s, h->w1_res[li], acts, W, F, wout, F, osk));
+    }
+  }
+  GSV_RC(mask_tail(wout));
+  GSV_RC(conv(h, s, h->w1_proj, wout, W, F, st, F, o));
+  GSV_RC(mask_tail(st));
+  GSV_DISPATCH(h,
+    hipLaunchKernelGGL(cl_to_cf_kernel<_Float16>, dim3(nblk((long long)F * W)), dim3(256), 0, s, (const _Float16*)st, F, W, 0, W, fea),
+    hipLaunchKernelGGL(cl_to_cf_kernel<float>, dim3(nblk((long long)F * W)), dim3(256), 0, s, (const float*)st, F, W, 0, W, fea));
+  GSV_HIP(hipGetLastError());
   return GSV_OK;
 }
 

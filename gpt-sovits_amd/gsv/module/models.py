@@ -16,13 +16,17 @@ from .. import _lib
 
 
 class SynthesizerTrn:
+    _VERSIONS = ("v1", "v2")
+    _FLAVOR = {"v1": 0, "v2": 0, "v3": 1, "v4": 2}
+
     def __init__(self, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads, n_layers,
                  kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
                  upsample_initial_channel, upsample_kernel_sizes, n_speakers=0, gin_channels=0, use_sdp=True,
                  semantic_frame_rate=None, freeze_quantizer=None, version="v2", device="cuda:0", dtype=torch.float16,
                  n_symbols: Optional[int] = None, **kwargs):
-        if version not in ("v1", "v2"):
-            raise NotImplementedError(f"SoVITS {version}: only the v1/v2 decoder is in the hot-path scope this round")
+        if version not in self._VERSIONS:
+            raise NotImplementedError(f"{type(self).__name__} does not implement SoVITS {version} (v2Pro is out of scope, "
+                                      "SURVEY section 8f)")
         if str(resblock) != "1":
             raise NotImplementedError("only ResBlock1 generators (reference configs/s2.json)")
         if semantic_frame_rate != "25hz":
@@ -56,6 +60,7 @@ class SynthesizerTrn:
             for c, d in enumerate(ds):
                 cfg.rb_dilations[j][c] = d
         cfg.ref_bins = spec_channels if version == "v1" else 704
+        cfg.flavor = self._FLAVOR[version]
         with torch.cuda.device(self.device):
             _lib.init(idx)
             h = C.c_void_p()
@@ -169,6 +174,58 @@ class SynthesizerTrn:
         a, b = C.c_float(0), C.c_float(0)
         _lib.check(_lib.lib().gsv_vits_last_timing(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+
+class SynthesizerTrnV3(SynthesizerTrn):
+    """Mirror of the reference's `SynthesizerTrnV3` inference interface (module/models.py:1128-1272) for v3 / v4:
+    `decode_encp` (enc_p -> bridge -> nearest x1.875 | x2 -> wns1) in the same HIP engine as v2's enc_p, and `cfm`,
+    the flow-matching decoder (`CFM` over `DiT`).  The checkpoint's `cfm.estimator.*` keys go to the DiT engine, the
+    rest to the encoder engine."""
+    _VERSIONS = ("v3", "v4")
+
+    def __init__(self, *args, version="v3", device="cuda:0", dtype=torch.float16, dit_kwargs: Optional[dict] = None, **kwargs):
+        super().__init__(*args, version=version, device=device, dtype=dtype, **kwargs)
+        from ..f5_tts.model.backbones.dit import DiT
+        dk = dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4)     # models.py:1219-1222
+        if dit_kwargs:
+            dk.update(dit_kwargs)
+        self.cfm = CFM(100, DiT(**dk, device=device, dtype=dtype))
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = False):
+        enc = {k: v for k, v in state_dict.items() if not k.startswith("cfm.")}
+        dit = {k: v for k, v in state_dict.items() if k.startswith("cfm.estimator.")}
+        super().load_state_dict(enc, strict)
+        self.cfm.estimator.load_state_dict(dit)
+        return self
+
+    def decode(self, *a, **k):
+        raise NotImplementedError("v3/v4 models synthesise through decode_encp + cfm.inference + a vocoder (TTS.py:1431-1494)")
+
+    @torch.no_grad()
+    def decode_encp(self, codes: torch.Tensor, text: torch.Tensor, refer, ge=None, speed: float = 1):
+        """reference models.py:1243-1267: codes [1,1,T], text [1,L], refer [1,bins,Tr] -> (fea [1,512,F], ge).
+        `ge` is the handle of the reference audio whose style vector is resident in the engine: pass the value a
+        previous call returned (with the same `refer`) to skip recomputing it, exactly like the reference."""
+        if not self._loaded:
+            raise RuntimeError("load_state_dict() first")
+        if codes.numel() == 0 or text.numel() == 0:
+            raise ValueError("decode_encp needs at least one semantic token and one phoneme")
+        T, L = int(codes.shape[-1]), int(text.shape[-1])
+        l = _lib.lib()
+        with torch.cuda.device(self.device):
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            if ge is None or ge != self._ref_key:
+                self._set_refer(refer)
+            F_ = l.gsv_vits_encp_frames(self._h, T, float(speed))
+            if F_ < 1:
+                raise ValueError(f"decode_encp: bad length / speed (T={T}, speed={speed})")
+            cd = codes.reshape(-1).to(self.device, torch.int32).contiguous()
+            tx = text.reshape(-1).to(self.device, torch.int32).contiguous()
+            fea = torch.empty(512, F_, dtype=torch.float32, device=self.device)
+            _lib.check(l.gsv_vits_decode_encp(self._h, cd.data_ptr(), T, tx.data_ptr(), L, float(speed), fea.data_ptr(),
+                                              C.c_void_p(self.stream.cuda_stream)), "gsv_vits_decode_encp")
+            self.stream.synchronize()
+        return fea.to(self.dtype).unsqueeze(0), self._ref_key
 
 
 class Generator:

@@ -487,3 +487,30 @@ def make_dit_state_dict(cfg: dict, seed: int = 0) -> "OrderedDict[str, torch.Ten
     lin("norm_out.linear", 2 * D, D, 0.5)
     lin("proj_out", md, D)
     return sd
+
+
+def make_vits_v3_state_dict(config=None, seed: int = 0, dit_cfg=None) -> "OrderedDict[str, torch.Tensor]":
+    """SynthesizerTrnV3 (reference module/models.py:1128-1226): the v2 enc_p / ref_enc / quantizer keys without flow / dec,
+    plus bridge, wns1 (Encoder 512/512/512, k5, 8 WN layers), linear_mel (training only) and, when `dit_cfg` is given,
+    `cfm.estimator.*`."""
+    cfg = config or VITS_V2_CONFIG
+    GIN = cfg["model"]["gin_channels"]
+    IC = cfg["model"]["inter_channels"]
+    sd = OrderedDict((k, v) for k, v in make_vits_state_dict(cfg, seed).items() if not k.startswith(("dec.", "flow.")))
+    W, NL = 512, 8
+    sd["bridge.0.weight"] = _w("bridge.0.weight", (W, IC, 1), IC, 1.5, seed)
+    sd["bridge.0.bias"] = _b("bridge.0.bias", W, 0.05, seed)
+    sd["wns1.pre.weight"] = _w("wns1.pre.weight", (W, W, 1), W, 1.0, seed)
+    sd["wns1.pre.bias"] = _b("wns1.pre.bias", W, 0.05, seed)
+    for li in range(NL):
+        _wn(sd, f"wns1.enc.in_layers.{li}", (2 * W, W, 5), W * 5, 1.0, seed)
+        _wn(sd, f"wns1.enc.res_skip_layers.{li}", (2 * W if li < NL - 1 else W, W, 1), W, 1.0, seed)
+    _wn(sd, "wns1.enc.cond_layer", (2 * W * NL, GIN, 1), GIN, 1.0, seed)
+    sd["wns1.proj.weight"] = _w("wns1.proj.weight", (W, W, 1), W, 1.0, seed)
+    sd["wns1.proj.bias"] = _b("wns1.proj.bias", W, 0.05, seed)
+    sd["linear_mel.weight"] = _w("linear_mel.weight", (100, W, 1), W, 1.0, seed)
+    sd["linear_mel.bias"] = _b("linear_mel.bias", 100, 0.05, seed)
+    if dit_cfg is not None:
+        for k, v in make_dit_state_dict(dit_cfg, seed).items():
+            sd["cfm.estimator." + k] = v
+    return sd

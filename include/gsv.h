@@ -115,6 +115,8 @@ typedef struct {
   int rb_kernels[4];
   int rb_dilations[4][3];
   int ref_bins;             /* 704 (v2): leading spectrogram bins fed to ref_enc */
+  int flavor;               /* 0 = v1/v2 SynthesizerTrn (flow + generator); 1 = v3, 2 = v4 SynthesizerTrnV3 (bridge + wns1,
+                               nearest x1.875 / x2; no flow / generator weights: the mel comes from gsv_cfm_inference) */
 } gsv_vits_config;
 
 int gsv_vits_create(const gsv_vits_config* cfg, int dtype, gsv_vits_t** out);
@@ -131,13 +133,19 @@ int gsv_vits_set_refer(gsv_vits_t* h, const float* const* specs, const int* fram
  * channels-first (the randn_like draw of models.py:1000; NULL = counter RNG keyed by seed),
  * wav [dev] fp32 [F * prod(up_rates)]. */
 int gsv_vits_decode(gsv_vits_t* h, const int32_t* codes, int T, const int32_t* phones, int L, const float* noise,
-                    float noise_scale, float speed, uint64_t seed, float* wav, gsv_stream_t stream);
+                    float noise_scale, double speed, uint64_t seed, float* wav, gsv_stream_t stream);
 /* ssl [dev] fp32 [ssl_dim][T50] channels-first -> codes [dev] int32 [T50/2] */
 int gsv_vits_extract_latent(gsv_vits_t* h, const float* ssl, int T50, int32_t* codes, gsv_stream_t stream);
 /* test hook: copy a named intermediate of the last decode ("ge","m_p","logs_p","z","stage0".."stage4")
  * into out [dev] fp32 in channels-first [C][T] order; returns element count via *numel. */
 int gsv_vits_debug_tensor(gsv_vits_t* h, const char* name, float* out, int64_t cap, int64_t* numel,
                           gsv_stream_t stream);
+/* v3 / v4 (H14, SynthesizerTrnV3.decode_encp, module/models.py:1243-1267): codes / phones as in gsv_vits_decode ->
+ * fea [dev] fp32 [512][F] (channels-first, what the reference returns; ge comes from gsv_vits_set_refer).
+ * F = gsv_vits_encp_frames(h, T, speed) = floor(frames_after_speed * (1.875 | 2)); returns -1 on bad arguments. */
+int gsv_vits_encp_frames(gsv_vits_t* h, int T, double speed);
+int gsv_vits_decode_encp(gsv_vits_t* h, const int32_t* codes, int T, const int32_t* phones, int L, double speed, float* fea,
+                         gsv_stream_t stream);
 /* per-kernel timing hooks for bench.py: device ms of the last decode's generator section */
 int gsv_vits_last_timing(gsv_vits_t* h, float* total_ms, float* generator_ms);
 

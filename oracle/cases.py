@@ -114,3 +114,21 @@ def cfm_case_inputs(case):
     prompt = S.hash_symmetric("cfm_prompt", (B, cfg["mel_dim"], Tp), 1.0, case["seed"])
     noise = S.hash_normal("cfm_noise", (B, cfg["mel_dim"], T), case["seed"])
     return cfg, sd, mu, prompt, noise
+
+
+ENCP_CASES = {
+    "encp_small_v3": dict(version="v3", seed=1, T=21, L=13, Tr=30, speed=1),
+    "encp_small_v4": dict(version="v4", seed=2, T=17, L=9, Tr=24, speed=1),
+    "encp_small_v3_speed": dict(version="v3", seed=3, T=3, L=5, Tr=20, speed=1.2),      # 1 masked tail frame
+    "encp_small_v4_speed": dict(version="v4", seed=4, T=9, L=7, Tr=20, speed=0.8),
+}
+
+
+def encp_case_inputs(case):
+    cfg = S.small_vits_config()
+    cfg["model"]["inter_channels"] = cfg["model"]["hidden_channels"]     # bridge is Conv1d(inter, 512) applied to the hidden sequence
+    sd = S.make_vits_v3_state_dict(cfg, seed=case["seed"])
+    codes = torch.from_numpy(S.hash_ints("codes", case["T"], 1024, case["seed"])).view(1, 1, -1)
+    text = torch.from_numpy(S.hash_ints("text", case["L"], cfg["n_symbols"], case["seed"])).view(1, -1)
+    refer = torch.from_numpy(S.hash_uniform("refer0", 1025 * case["Tr"], case["seed"]).reshape(1, 1025, case["Tr"]).copy())
+    return cfg, sd, codes, text, refer

@@ -110,7 +110,7 @@ def gen_t2s():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["t2s", "vits", "aa", "voc", "cfm"]
+    what = sys.argv[1:] or ["t2s", "vits", "aa", "voc", "cfm", "encp"]
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -125,6 +125,9 @@ if __name__ == "__main__":
     if "voc" in what:
         from oracle.gen_golden_vits import gen_voc
         gen_voc()
+    if "encp" in what:
+        from oracle.gen_golden_vits import gen_encp
+        gen_encp()
     if "cfm" in what:
         from oracle.gen_golden_vits import gen_cfm
         gen_cfm()

@@ -156,3 +156,26 @@ def gen_cfm():
               f"oracle max-abs err {err:.2e}")
         assert err <= 2e-4
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), mel=ref.numpy().astype(np.float32))
+
+
+def gen_encp():
+    """SynthesizerTrnV3.decode_encp (reference class, v3 and v4 scale factors) vs the oracle."""
+    from oracle.cases import ENCP_CASES, encp_case_inputs
+    ref_import.setup()
+    from module.models import SynthesizerTrnV3
+    for name, case in ENCP_CASES.items():
+        cfg, sd, codes, text, refer = encp_case_inputs(case)
+        d = cfg["data"]
+        model = SynthesizerTrnV3(d["filter_length"] // 2 + 1, cfg["train"]["segment_size"] // d["hop_length"],
+                                 n_speakers=d["n_speakers"], version=case["version"], **cfg["model"])
+        res = model.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys and all(k.startswith("cfm.") for k in res.missing_keys), res
+        model.eval()
+        with torch.no_grad():
+            ref, ge = model.decode_encp(codes, text, refer, speed=case["speed"])
+        out, oge = VitsOracle(sd, cfg).decode_encp(codes, text, refer, speed=case["speed"], version=case["version"])
+        err = (out - ref).abs().max().item()
+        print(f"[gen_golden] {name}: fea {tuple(ref.shape)} absmax {ref.abs().max():.3f} rms {ref.pow(2).mean().sqrt():.3f} "
+              f"oracle max-abs err {err:.2e}")
+        assert out.shape == ref.shape and err <= 1e-4
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), fea=ref.numpy().astype(np.float32))

@@ -154,7 +154,7 @@ class VitsOracle:
         x = self.conv(o, p + ".cross_attention.conv_o") + s + ge
         return self.conv(x, p + ".c_post")
 
-    def enc_p(self, quantized, text_ids, ge, speed=1):
+    def enc_p(self, quantized, text_ids, ge, speed=1, hidden_only=False):
         y = self.conv(quantized, "enc_p.ssl_proj")
         y = self._encoder(y, "enc_p.encoder_ssl", self.n_layers // 2)
         t = self.sd["enc_p.text_embedding.weight"][text_ids].t()
@@ -163,8 +163,40 @@ class VitsOracle:
         y = self._encoder(y, "enc_p.encoder2", self.n_layers // 2)
         if speed != 1:   # models.py:226-228
             y = F.interpolate(y.unsqueeze(0), size=int(y.shape[-1] / speed) + 1, mode="linear")[0]
+        if hidden_only:
+            return y
         stats = self.conv(y, "enc_p.proj")
         return stats[: self.inter], stats[self.inter:]
+
+    # ---- H14 (v3 / v4) ----------------------------------------------------------
+    @torch.no_grad()
+    def decode_encp(self, codes: torch.Tensor, text: torch.Tensor, refer: torch.Tensor, speed: float = 1, version: str = "v3"):
+        """SynthesizerTrnV3.decode_encp (models.py:1243-1267): enc_p hidden -> bridge (1x1 + LeakyReLU 0.01) -> nearest
+        x1.875 (v3) / x2 (v4) -> wns1 = Encoder(512, 512, 512, 5, 1, 8) with its length mask (models.py:340-364)."""
+        ge = self.ref_enc(refer)
+        T = codes.shape[-1]
+        q = self.sd["quantizer.vq.layers.0._codebook.embed"][codes[0, 0].long()].t().repeat_interleave(2, dim=1)
+        y = self.enc_p(q, text[0].long(), ge, speed, hidden_only=True)
+        fea = F.leaky_relu(self.conv(y, "bridge.0"), 0.01)
+        fea = F.interpolate(fea.unsqueeze(0), scale_factor=(1.875 if version == "v3" else 2), mode="nearest")[0]
+        per = 3.875 if version == "v3" else 4
+        sizee = int(T * per) if speed == 1 else int(T * per / speed) + 1
+        mask = (torch.arange(fea.shape[-1]) < sizee).to(fea.dtype).unsqueeze(0)
+        W, NL = 512, 8
+        x = self.conv(fea, "wns1.pre") * mask
+        out = torch.zeros_like(x)
+        gc = self.conv(ge, "wns1.enc.cond_layer")
+        for i in range(NL):                                               # modules.WN.forward (modules.py:182-207)
+            xin = self.conv(x, f"wns1.enc.in_layers.{i}") + gc[i * 2 * W:(i + 1) * 2 * W]
+            acts = torch.tanh(xin[:W]) * torch.sigmoid(xin[W:])
+            rs = self.conv(acts, f"wns1.enc.res_skip_layers.{i}")
+            if i < NL - 1:
+                x = (x + rs[:W]) * mask
+                out = out + rs[W:]
+            else:
+                out = out + rs
+        out = out * mask
+        return (self.conv(out, "wns1.proj") * mask).unsqueeze(0), ge
 
     # ---- H11 ------------------------------------------------------------------
     def _wn(self, x, g, prefix):

@@ -63,3 +63,38 @@ def test_cfm_device_noise_and_errors():
         cfm.inference(mu[:, :4].to(DEV), None, prompt.to(DEV), 2)          # prompt longer than the sequence
     with pytest.raises(NotImplementedError):
         cfm.inference(mu.to(DEV), None, prompt.to(DEV), 2, inference_cfg_rate=0.5)
+
+
+def _v3(cfg, sd, version, dtype):
+    from gsv.module.models import SynthesizerTrnV3
+    from gsv import synthetic as S
+    d = cfg["data"]
+    dit = S.small_dit_config()
+    dit["text_dim"] = 512
+    m = SynthesizerTrnV3(d["filter_length"] // 2 + 1, cfg["train"]["segment_size"] // d["hop_length"],
+                         n_speakers=d["n_speakers"], version=version, device=DEV, dtype=dtype, n_symbols=cfg["n_symbols"],
+                         dit_kwargs={k: v for k, v in dit.items() if k != "mel_dim"}, **cfg["model"])
+    full = dict(sd)
+    full.update({"cfm.estimator." + k: v for k, v in S.make_dit_state_dict(dit, seed=0).items()})
+    m.load_state_dict(full)
+    return m
+
+
+@pytest.mark.parametrize("name", list(cases.ENCP_CASES))
+def test_decode_encp_matches_reference(name):
+    """SynthesizerTrnV3.decode_encp (enc_p -> bridge -> nearest x1.875 | x2 -> wns1 with its tail mask), fp32 engine vs
+    the reference class (golden): max-abs <= 5e-4 on features of rms ~1.1; fp16 engine: relative RMS <= 2 %."""
+    case = cases.ENCP_CASES[name]
+    cfg, sd, codes, text, refer = cases.encp_case_inputs(case)
+    g = load_golden(name)["fea"]
+    m = _v3(cfg, sd, case["version"], torch.float32)
+    fea, ge = m.decode_encp(codes.to(DEV), text.to(DEV), refer.to(DEV), speed=case["speed"])
+    assert tuple(fea.shape) == g.shape
+    assert np.abs(fea.cpu().numpy() - g).max() <= 5e-4
+    fea2, ge2 = m.decode_encp(codes.to(DEV), text.to(DEV), refer.to(DEV), ge=ge, speed=case["speed"])     # cached ge
+    assert torch.equal(fea, fea2) and ge2 == ge
+    m16 = _v3(cfg, sd, case["version"], torch.float16)
+    f16 = m16.decode_encp(codes.to(DEV), text.to(DEV), refer.to(DEV), speed=case["speed"])[0].float().cpu().numpy()
+    assert np.sqrt(((f16 - g) ** 2).mean()) <= 0.02 * np.sqrt((g ** 2).mean())
+    with pytest.raises(NotImplementedError):
+        m.decode(codes.to(DEV), text.to(DEV), refer.to(DEV))
