@@ -1,6 +1,7 @@
 """Host-side mirror of the reference pipeline API `TTS_infer_pack.TTS` (reference
 GPT_SoVITS/TTS_infer_pack/TTS.py: `TTS_Config`:217, `TTS`:412, `run`:984, `to_batch`:842,
-`recovery_order`:957, `audio_postprocess`:1377), v1/v2 path, on the HIP engines.
+`recovery_order`:957, `audio_postprocess`:1377, `using_vocoder_synthesis`:1431, `..._batched_infer`:1496,
+`sola_algorithm`:1611), v1/v2 and v3/v4 paths, on the HIP engines.
 
 What is kept: the `run(inputs) -> generator of (sr, int16 ndarray)` contract with the reference's
 keys and defaults, length-bucketed batching, AR -> one time-axis-concatenated `decode` per batch,
@@ -23,9 +24,21 @@ from typing import Callable, Dict, Generator, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from ..AR.models.t2s_model import Text2SemanticDecoder
-from ..module.models import SynthesizerTrn
+from ..module.models import SynthesizerTrn, SynthesizerTrnV3
+
+
+spec_min, spec_max = -12, 2          # reference TTS.py:55-56
+
+
+def norm_spec(x):
+    return (x - spec_min) / (spec_max - spec_min) * 2 - 1
+
+
+def denorm_spec(x):
+    return (x + 1) / 2 * (spec_max - spec_min) + spec_min
 
 
 class NO_PROMPT_ERROR(Exception):
@@ -57,13 +70,13 @@ class TTS_Config:
         self.device = torch.device(configs.get("device", "cuda:0"))
         self.is_half = bool(configs.get("is_half", True))
         self.version = configs.get("version", "v2")
-        if self.version not in ("v1", "v2"):
-            raise NotImplementedError(f"version {self.version}: the v1/v2 pipeline is the scope of this build")
+        if self.version not in ("v1", "v2", "v3", "v4"):
+            raise NotImplementedError(f"version {self.version}: v1 / v2 / v3 / v4 are built; v2Pro(Plus) is out of scope")
         self.t2s_weights_path = configs.get("t2s_weights_path")
         self.vits_weights_path = configs.get("vits_weights_path")
         self.max_batch = int(configs.get("max_batch", 32))
         self.max_seq = int(configs.get("max_seq", 2048))
-        self.use_vocoder = False
+        self.use_vocoder = self.version in ("v3", "v4")     # TTS.py:519-521
         self.max_sec = None
         self.hz: int = 50
         self.semantic_frame_rate: str = "25hz"
@@ -94,6 +107,8 @@ class TTS:
         self.precision = self.configs.precision
         self._t2s_state = None
         self._vits_state = None
+        self.vocoder = None
+        self.vocoder_configs: dict = {"sr": None, "T_ref": None, "T_chunk": None, "upsample_rate": None, "overlapped_len": None}
 
     # ---- weights (reference TTS.py:484-603) ------------------------------------------------
     def init_t2s_weights(self, weights_path: Optional[str] = None, state: Optional[dict] = None):
@@ -124,16 +139,59 @@ class TTS:
         self.configs.win_length = d["win_length"]
         self.configs.n_speakers = d["n_speakers"]
         self.configs.vits_weights_path = weights_path
-        v = SynthesizerTrn(d["filter_length"] // 2 + 1, hps["train"]["segment_size"] // d["hop_length"],
-                           n_speakers=d["n_speakers"], version=self.configs.version, device=self.configs.device,
-                           dtype=self.precision, n_symbols=hps.get("n_symbols"), **mcfg)
+        extra = {}
+        cls = SynthesizerTrn
+        if self.configs.use_vocoder:
+            cls = SynthesizerTrnV3
+            if "dit" in hps:             # synthetic / test checkpoints may carry a smaller DiT than models.py:1219-1222
+                extra["dit_kwargs"] = hps["dit"]
+        v = cls(d["filter_length"] // 2 + 1, hps["train"]["segment_size"] // d["hop_length"],
+                n_speakers=d["n_speakers"], version=self.configs.version, device=self.configs.device,
+                dtype=self.precision, n_symbols=hps.get("n_symbols"), **extra, **mcfg)
         v.load_state_dict(state["weight"])
         self.vits_model = v
+
+    def init_vocoder(self, version: Optional[str] = None, state: Optional[dict] = None, weights_path: Optional[str] = None):
+        """reference TTS.py:605-660: v3 -> BigVGAN-v2 24 kHz x256, v4 -> the HiFi-GAN `Generator` 48 kHz x480.
+        `state` = {"config": vocoder hyper-parameters, "weight": state dict} (or a file holding the state dict)."""
+        version = version or self.configs.version
+        if state is None:
+            state = {"weight": torch.load(weights_path, map_location="cpu", weights_only=True), "config": None}
+        cfg = state.get("config")
+        if version == "v3":
+            from ..BigVGAN.bigvgan import BigVGAN
+            from .. import synthetic as S
+            h = dict(cfg or S.BIGVGAN_V2_24K_CONFIG)
+            self.vocoder = BigVGAN(h, device=self.configs.device, dtype=self.precision)
+            self.vocoder.load_state_dict(state["weight"])
+            self.vocoder_configs.update(sr=24000, T_ref=468, T_chunk=934, upsample_rate=256, overlapped_len=12)
+        elif version == "v4":
+            from ..module.models import Generator as HifiGenerator
+            from .. import synthetic as S
+            h = dict(cfg or S.HIFIGAN_V4_CONFIG)
+            self.vocoder = HifiGenerator(initial_channel=100, resblock="1", resblock_kernel_sizes=h["resblock_kernel_sizes"],
+                                         resblock_dilation_sizes=h["resblock_dilation_sizes"], upsample_rates=h["upsample_rates"],
+                                         upsample_initial_channel=h["upsample_initial_channel"],
+                                         upsample_kernel_sizes=h["upsample_kernel_sizes"], gin_channels=0, is_bias=True,
+                                         device=self.configs.device, dtype=self.precision)
+            self.vocoder.load_state_dict(state["weight"])
+            self.vocoder_configs.update(sr=48000, T_ref=500, T_chunk=1000, upsample_rate=480, overlapped_len=12)
+        else:
+            raise ValueError(f"no vocoder for version {version}")
+        up = math.prod(h["upsample_rates"])
+        if up != self.vocoder_configs["upsample_rate"]:      # reduced test vocoders
+            self.vocoder_configs["upsample_rate"] = up
+        for k in ("T_ref", "T_chunk", "overlapped_len", "sr"):
+            if cfg and k in cfg:
+                self.vocoder_configs[k] = cfg[k]
 
     # ---- prompt cache (replaces set_ref_audio's HuBERT/STFT front-end, TTS.py:737-819) ---------
     def set_prompt_cache(self, prompt_semantic: torch.Tensor, refer_spec: Sequence[torch.Tensor],
                          phones: Optional[List[int]] = None, bert_features: Optional[torch.Tensor] = None,
-                         norm_text: str = ""):
+                         norm_text: str = "", ref_mel: Optional[torch.Tensor] = None):
+        """`ref_mel` (v3/v4 only): the log-mel of the reference audio as `mel_fn` / `mel_fn_v4` return it ([1, 100, Tm],
+        TTS.py:67-88, 1453) -- computing it from the waveform is part of the audio front-end, outside this build."""
+        self.prompt_cache["ref_mel"] = ref_mel
         self.prompt_cache["prompt_semantic"] = prompt_semantic.to(self.configs.device)
         self.prompt_cache["refer_spec"] = [(s, None) for s in refer_spec]
         self.prompt_cache["phones"] = phones
@@ -256,6 +314,115 @@ class TTS:
         pcm = (wav * 32768).to(torch.int32).to(torch.int16)
         return sr, pcm.cpu().numpy()
 
+
+    # ---- v3 / v4 synthesis (reference TTS.py:1431-1637) -----------------------------------------
+    def _prompt_features(self):
+        pc = self.prompt_cache
+        if pc.get("ref_mel") is None or pc["phones"] is None:
+            raise NO_PROMPT_ERROR("v3/v4 need set_prompt_cache(..., phones=..., ref_mel=...)")
+        dev = self.configs.device
+        spec = pc["refer_spec"][0]
+        spec = spec[0] if isinstance(spec, tuple) else spec
+        spec = spec.to(dev)
+        fea_ref, ge = self.vits_model.decode_encp(pc["prompt_semantic"].view(1, 1, -1), torch.as_tensor(pc["phones"]).view(1, -1), spec)
+        mel2 = norm_spec(pc["ref_mel"].to(dev, torch.float32))
+        T_min = min(mel2.shape[2], fea_ref.shape[2])
+        mel2, fea_ref = mel2[:, :, :T_min], fea_ref[:, :, :T_min]
+        T_ref = self.vocoder_configs["T_ref"]
+        if T_min > T_ref:
+            mel2, fea_ref, T_min = mel2[:, :, -T_ref:], fea_ref[:, :, -T_ref:], T_ref
+        return spec, fea_ref, ge, mel2.to(self.precision), T_min
+
+    @torch.no_grad()
+    def using_vocoder_synthesis(self, semantic_tokens: torch.Tensor, phones: torch.Tensor, speed: float = 1.0,
+                                sample_steps: int = 32, seed: int = 0, noise_fn: Optional[Callable] = None) -> torch.Tensor:
+        """TTS.py:1431-1494: one fragment; the mel is generated chunk by chunk, each chunk prompted with the tail of the
+        previous one.  `noise_fn(call_index, shape)` (tests) pins the randn draw of each cfm.inference call."""
+        spec, fea_ref, ge, mel2, T_min = self._prompt_features()
+        chunk_len = self.vocoder_configs["T_chunk"] - T_min
+        fea_todo, ge = self.vits_model.decode_encp(semantic_tokens, phones, spec, ge, speed)
+        outs, pos, call = [], 0, 0
+        while True:
+            chunk = fea_todo[:, :, pos:pos + chunk_len]
+            if chunk.shape[-1] == 0:
+                break
+            pos += chunk_len
+            fea = torch.cat([fea_ref, chunk], 2).transpose(2, 1)
+            nz = noise_fn(call, (1, 100, fea.shape[1])) if noise_fn else None
+            res = self.vits_model.cfm.inference(fea, None, mel2, sample_steps, inference_cfg_rate=0, noise=nz, seed=seed + call)
+            res = res[:, :, mel2.shape[2]:]
+            call += 1
+            mel2 = res[:, :, -T_min:]
+            fea_ref = chunk[:, :, -T_min:]
+            outs.append(res)
+        return self.vocoder(denorm_spec(torch.cat(outs, 2)))[0][0]
+
+    @torch.no_grad()
+    def using_vocoder_synthesis_batched_infer(self, idx_list: List[int], semantic_tokens_list: List[torch.Tensor],
+                                              batch_phones: List[torch.Tensor], speed: float = 1.0, sample_steps: int = 32,
+                                              seed: int = 0, noise_fn: Optional[Callable] = None) -> List[torch.Tensor]:
+        """TTS.py:1496-1609: all fragments of a batch concatenated, cut into overlapping chunks that go through ONE
+        batched cfm.inference, vocoded as one sequence, re-joined with SOLA and split back per fragment."""
+        spec, fea_ref, ge, mel2, T_min = self._prompt_features()
+        vc = self.vocoder_configs
+        chunk_len = vc["T_chunk"] - T_min
+        ov, up = vc["overlapped_len"], vc["upsample_rate"]
+        feats, lens = [], []
+        for i, idx in enumerate(idx_list):
+            f, _ = self.vits_model.decode_encp(semantic_tokens_list[i][-idx:].view(1, 1, -1), batch_phones[i].view(1, -1), spec, ge, speed)
+            feats.append(f)
+            lens.append(int(f.shape[2]))
+        padded = F.pad(torch.cat(feats, 2), (ov, 0))
+        chunks, pos, pad_len = [], 0, 0
+        while True:
+            if pos != 0:
+                pos -= ov
+            chunk = padded[:, :, pos:pos + chunk_len]
+            pos += chunk_len
+            if chunk.shape[-1] == 0:
+                break
+            pad_len = chunk_len - chunk.shape[2]
+            if pad_len:
+                chunk = F.pad(chunk, (0, pad_len))
+            chunks.append(chunk)
+        chunks = torch.cat(chunks, 0)
+        bs = chunks.shape[0]
+        fea = torch.cat([fea_ref.repeat(bs, 1, 1), chunks], 2).transpose(2, 1)
+        nz = noise_fn(0, (bs, 100, fea.shape[1])) if noise_fn else None
+        pred = self.vits_model.cfm.inference(fea, None, mel2, sample_steps, inference_cfg_rate=0, noise=nz, seed=seed)
+        pred = pred[:, :, -chunk_len:]
+        pred = pred.permute(1, 0, 2).contiguous().view(pred.shape[1], -1).unsqueeze(0)
+        audio = self.vocoder(denorm_spec(pred))[0][0]
+        pieces, p = [], 0
+        while p < audio.shape[-1]:
+            pieces.append(audio[p:p + chunk_len * up])
+            p += chunk_len * up
+        audio = self.sola_algorithm(pieces, ov * up)
+        audio = audio[ov * up:-pad_len * up]      # as written in the reference (TTS.py:1600): empty when pad_len == 0
+        out = []
+        for n in lens:
+            out.append(audio[:n * up])
+            audio = audio[n * up:]
+        return out
+
+    def sola_algorithm(self, audio_fragments: List[torch.Tensor], overlap_len: int) -> torch.Tensor:
+        """TTS.py:1611-1637 on the device (`gsv_sola`, csrc/sola.hip): correlation, argmax and cross-fade per
+        neighbouring pair, then one compaction; only the stitched length returns to the host."""
+        import ctypes as C
+        from .. import _lib
+        dev = self.configs.device
+        dt = audio_fragments[0].dtype
+        lens = [int(f.shape[0]) for f in audio_fragments]
+        with torch.cuda.device(dev):
+            buf = torch.cat([f.to(dev, torch.float32) for f in audio_fragments]).contiguous()
+            out = torch.empty_like(buf)
+            n_out = C.c_int(0)
+            arr = (C.c_int * len(lens))(*lens)
+            st = torch.cuda.current_stream(dev)
+            _lib.check(_lib.lib().gsv_sola(buf.data_ptr(), arr, len(lens), int(overlap_len), out.data_ptr(), C.byref(n_out),
+                                           C.c_void_p(st.cuda_stream)), "gsv_sola")
+        return out[:n_out.value].to(dt)
+
     # ---- the pipeline (reference TTS.py:984-1365) ---------------------------------------------
     @torch.no_grad()
     def run(self, inputs: dict) -> Generator[Tuple[int, np.ndarray], None, None]:
@@ -311,7 +478,9 @@ class TTS:
             refer = [spec.to(device=self.configs.device) for spec, _ in self.prompt_cache["refer_spec"]]
             up = math.prod(self.vits_model.upsample_rates)
             audio, t_34, t_45 = [], 0.0, 0.0
-            sr = self.configs.sampling_rate
+            sr = self.configs.sampling_rate if not self.configs.use_vocoder else self.vocoder_configs["sr"]
+            if self.configs.use_vocoder and self.vocoder is None:
+                raise RuntimeError("init_vocoder() first")
             self.last_generated_tokens = 0
             for bi, item in enumerate(data):
                 t3 = time.perf_counter()
@@ -328,7 +497,19 @@ class TTS:
                 pred = [p[-i:] if i > 0 else p[:0] for p, i in zip(pred_list, idx_list)]
                 self.last_generated_tokens += int(sum(idx_list))
                 frags: List[torch.Tensor] = []
-                if speed_factor == 1.0:
+                if self.configs.use_vocoder:
+                    # TTS.py:1283-1299
+                    sample_steps = inputs.get("sample_steps", 32)
+                    dev_ph = [ph.to(self.configs.device) for ph in item["phones"]]
+                    if parallel_infer:
+                        frags = self.using_vocoder_synthesis_batched_infer(idx_list, pred_list, dev_ph, speed=speed_factor,
+                                                                           sample_steps=sample_steps, seed=actual_seed + bi)
+                    else:
+                        for k, idx in enumerate(idx_list):
+                            frags.append(self.using_vocoder_synthesis(pred_list[k][-idx:].view(1, 1, -1), dev_ph[k].view(1, -1),
+                                                                      speed=speed_factor, sample_steps=sample_steps,
+                                                                      seed=actual_seed + bi * 4096 + k))
+                elif speed_factor == 1.0:
                     # one decode over the batch folded into the time axis (TTS.py:1259-1282)
                     ends = np.cumsum([0] + [int(p.shape[0]) * 2 * up for p in pred])
                     keep = [k for k, p in enumerate(pred) if p.shape[0] > 0]

@@ -286,8 +286,10 @@ class CFM:
         if mu.dim() != 3 or mu.shape[2] != dit.text_dim or mu.shape[1] < 1:
             raise ValueError(f"expected mu of shape [B, T>=1, {dit.text_dim}], got {tuple(mu.shape)}")
         B, T = int(mu.shape[0]), int(mu.shape[1])
-        if prompt.dim() != 3 or prompt.shape[0] != B or prompt.shape[1] != self.in_channels or prompt.shape[2] > T:
-            raise ValueError(f"expected prompt of shape [{B}, {self.in_channels}, Tp<={T}], got {tuple(prompt.shape)}")
+        if prompt.dim() != 3 or prompt.shape[0] not in (1, B) or prompt.shape[1] != self.in_channels or prompt.shape[2] > T:
+            raise ValueError(f"expected prompt of shape [{B} or 1, {self.in_channels}, Tp<={T}], got {tuple(prompt.shape)}")
+        if prompt.shape[0] != B:           # one prompt broadcast over the batch (models.py:1036 assigns it into every row)
+            prompt = prompt.expand(B, -1, -1)
         Tp = int(prompt.shape[2])
         if noise is not None and tuple(noise.shape) != (B, self.in_channels, T):
             raise ValueError(f"noise must have shape {(B, self.in_channels, T)}")

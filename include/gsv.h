@@ -205,6 +205,14 @@ int gsv_cfm_inference(gsv_cfm_t* h, const float* mu, const float* prompt, int B,
                       const float* noise, float temperature, uint64_t seed, float* out, gsv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * SOLA stitching of the chunked v3/v4 vocoder output (H17, TTS.sola_algorithm, TTS_infer_pack/TTS.py:1611-1637).
+ * frags [dev] fp32: the n fragments back to back (lens [host] samples each, every one >= 2 * overlap); modified in
+ * place (cross-faded heads).  out [dev] fp32, capacity sum(lens); *out_len [host] = stitched length.  Synchronises
+ * the stream (the length depends on the argmax offsets found on the device).
+ * ------------------------------------------------------------------------------------- */
+int gsv_sola(float* frags, const int* lens, int n, int overlap, float* out, int* out_len, gsv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * BigVGAN anti-aliased snake activation (v3 vocoder), the reference's one native kernel.
  * x,y [dev] [B][C][T] of `dtype`; up12/dn12 [dev] 12 filter taps; log_alpha/log_beta [dev] [C].
  * T == 0 returns GSV_OK without a launch (anti_alias_activation_cuda.cu:193-196).
