@@ -88,8 +88,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
   const int env = max(0, min(4, a.Cout - ec));
   f4 ebias = (f4){0.f, 0.f, 0.f, 0.f};
   if (a.bias) for (int j = 0; j < env; ++j) ebias[j] = a.bias[eoc + j];
-  f4 egate = (f4){1.f, 1.f, 1.f, 1.f};
-  if (a.gate) for (int j = 0; j < env; ++j) egate[j] = a.gate[eoc + j];
   // the wide tile (CT = 128) keeps only the residual in registers; its accumulate operand is fetched per
   // pass (that tile has ~19 us of MFMA work, the narrow ones have <2 us and must not stall at all)
   constexpr bool PRE_ACC = ACCU && CT < 128;
@@ -275,7 +273,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float u = (av[j] + ebias[j]) * egate[j];
+        float u = av[j] + ebias[j];
         if (RES) u += to_f(rv[q][j]);
         u *= a.scale;
         u = post_act_f(a.post_act, u);
@@ -529,7 +527,7 @@ template <typename T> static int try_launch(const ConvArgs& a, hipStream_t s) {
   constexpr int G = DT<T>::G;
   constexpr int KC = 2 * G;
   constexpr int CCBIG = 256 / (int)sizeof(T);   // 128 fp16 / 64 fp32 input channels per chunk
-  if (a.Z != 1 || a.stride != 1 || a.Cin % KC != 0 || a.T_virt < 256) return 1;
+  if (a.Z != 1 || a.stride != 1 || a.Cin % KC != 0 || a.T_virt < 256 || a.gate) return 1;   // gate: 1x1 (gemm) epilogues only
   if ((a.res && a.res_f32) || (a.accumulate && a.out_f32)) return 1;   // preloaded operands are engine-dtype tiles
   if (a.ldx % G != 0 || a.ldw % G != 0 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return 1;
   const int span = (a.taps - 1) * (a.dil < 0 ? -a.dil : a.dil);
