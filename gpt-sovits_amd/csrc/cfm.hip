@@ -225,6 +225,7 @@ struct gsv_cfm {
   std::vector<TextBlockW> text;
   std::vector<DitBlockW> blocks;
   float* pos_table = nullptr;   // fp32 [4096][text_dim]
+  bool materialized_attn = false;   // GSV_CFM_MATERIALIZED_ATTN=1: A/B switch back to the 4-launch scores/softmax/PV path
 };
 
 #define CFM_LAUNCH(kern, n, ...)                                                                         \
@@ -351,8 +352,15 @@ int cfm_infer_one(gsv_cfm* c, hipStream_t s, const float* mods, const float* mu,
       hipLaunchKernelGGL(cfm_ln_mod_kernel<T>, dim3(cdiv(Tn, 4)), dim3(256), 0, s, (const T*)hb, m + D, m, Tn, D, (T*)nrm);
       GSV_RC(conv(h, s, b.qkv, nrm, D, Tn, qkv, Tn, o));
       CFM_LAUNCH(cfm_rope_kernel<T>, Tn * half * 2, (T*)qkv, 3 * inner, inner, Tn, half, cs);
-      GSV_RC(attention(h, s, qkv, 3 * inner, 0, qkv, 3 * inner, inner, 2 * inner, Tn, Tn, g.heads, g.dim_head, att_scale, nullptr,
-                       nullptr, ao, inner));
+      if (h->dtype == GSV_F16 && g.dim_head == 64 && !c->materialized_attn) {
+        void* vtb;
+        GSV_RC(need(h, "cfm_vt", (size_t)g.heads * 64 * ((Tn + 31) / 32 * 32) * 2, &vtb));
+        GSV_RC(launch_flash_attn64_f16(qkv, 3 * inner, (const _Float16*)qkv + inner, 3 * inner, (const _Float16*)qkv + 2 * inner, 3 * inner,
+                                       vtb, Tn, g.heads, att_scale, ao, inner, s));
+      } else {
+        GSV_RC(attention(h, s, qkv, 3 * inner, 0, qkv, 3 * inner, inner, 2 * inner, Tn, Tn, g.heads, g.dim_head, att_scale, nullptr,
+                         nullptr, ao, inner));
+      }
       ConvOpt og; og.gate = m + 2 * D; og.res = hb;
       GSV_RC(conv(h, s, b.out, ao, inner, Tn, hb, Tn, og));
       hipLaunchKernelGGL(cfm_ln_mod_kernel<T>, dim3(cdiv(Tn, 4)), dim3(256), 0, s, (const T*)hb, m + 4 * D, m + 3 * D, Tn, D, (T*)nrm);
@@ -387,6 +395,8 @@ int gsv_cfm_create(const gsv_dit_config* cfg, int dtype, gsv_cfm_t** out) {
   gsv_cfm* c = new gsv_cfm();
   c->cfg = *cfg;
   c->ctx.dtype = dtype;
+  const char* e = getenv("GSV_CFM_MATERIALIZED_ATTN");
+  c->materialized_attn = e && e[0] == '1';
   *out = c;
   return GSV_OK;
 }

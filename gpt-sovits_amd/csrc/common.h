@@ -121,6 +121,10 @@ int launch_conv_gemm(int dtype, const ConvArgs& a, hipStream_t s);
 // LDS-staged variant for stride-1 convs (conv_lds.hip): 0 = launched, 1 = not eligible, <0 = error
 int launch_conv_lds(int dtype, const ConvArgs& a, hipStream_t s);
 
+// fused attention, fp16, head dim 64 (attn.hip); vt_buf: heads * 64 * ceil32(T) halfs of scratch
+int launch_flash_attn64_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* vt_buf, int T, int heads,
+                            float scale, void* out, int ldo, hipStream_t s);
+
 // elementwise / small ops (ops.hip)
 int launch_layernorm(int dtype, const void* x, int x_f32, const void* res, int res_f32, const float* gamma,
                      const float* beta, void* y, int y_f32, int rows, int C, float eps, hipStream_t s);

@@ -108,6 +108,12 @@ int gsv_op_layernorm(const void* x, const void* res, const float* gamma, const f
   return gsv::launch_layernorm(dtype, x, 0, res, 0, gamma, beta, y, 0, rows, C, eps, (hipStream_t)stream);
 }
 
+int gsv_op_flash_attn64(const void* qkv, int T, int heads, float scale, void* vt_scratch, void* out, gsv_stream_t stream) {
+  const int inner = heads * 64;
+  return gsv::launch_flash_attn64_f16(qkv, 3 * inner, (const _Float16*)qkv + inner, 3 * inner, (const _Float16*)qkv + 2 * inner, 3 * inner,
+                                      vt_scratch, T, heads, scale, out, inner, (hipStream_t)stream);
+}
+
 int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream) {
   gsv::ConvArgs a;
   a.x = d->x; a.w = d->w; a.bias = d->bias; a.y = d->y; a.res = d->res;

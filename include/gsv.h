@@ -231,6 +231,9 @@ typedef struct {
   /* optional (0 = defaults): batched GEMM over Z slices with element strides, explicit leading dims */
   int Z; long long xz, wz, yz; int ldx, ldw, ldy;
 } gsv_conv_desc;
+/* fused softmax attention of the DiT blocks alone (fp16, head dim 64): qkv [dev] f16 [T][3*heads*64] (q | k | v column
+ * blocks), vt_scratch [dev] heads*64*ceil32(T) halfs, out [dev] f16 [T][heads*64] */
+int gsv_op_flash_attn64(const void* qkv, int T, int heads, float scale, void* vt_scratch, void* out, gsv_stream_t stream);
 /* channels-last conv1d: x [T_in][Cin], w [Cout][taps*Cin] (tap-major, cin fastest), y [T_out][Cout] */
 int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream);
 /* y = LN(x (+res)) over the last dim C; all buffers of `dtype`, gamma/beta fp32 */

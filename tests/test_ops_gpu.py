@@ -211,3 +211,23 @@ def test_batched_attention_gemms(dtype, tol, Tq, Tk, nh, kc):
     torch.cuda.synchronize()
     ref2 = torch.einsum("hqk,khc->qhc", P[:, :, :Tk], v.view(Tk, nh, kc)).reshape(Tq, H)
     assert (out.float().cpu() - ref2).abs().max().item() < tol * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("T,heads", [(934, 16), (33, 2), (16, 1), (1, 1), (129, 3)])
+def test_flash_attention_matches_sdpa(T, heads):
+    """fused DiT attention (fp16, d=64) vs torch fp32 softmax(QK^T/8)V on the same fp16-rounded inputs: max-abs <= 4e-3
+    (fp16 probabilities / output rounding), including ragged T (partial key chunks, partial query tiles)."""
+    from gsv import _lib
+    from gsv import synthetic as S
+    _lib.init(0)
+    inner = heads * 64
+    qkv = (S.hash_symmetric(f"fa_qkv_{T}", (T, 3 * inner), 1.5, 2)).to(DEV, torch.float16)
+    vt = torch.empty(heads * 64 * ((T + 31) // 32 * 32), dtype=torch.float16, device=DEV)
+    out = torch.empty(T, inner, dtype=torch.float16, device=DEV)
+    st = torch.cuda.current_stream()
+    _lib.check(_lib.lib().gsv_op_flash_attn64(qkv.data_ptr(), T, heads, 0.125, vt.data_ptr(), out.data_ptr(), C.c_void_p(st.cuda_stream)))
+    torch.cuda.synchronize()
+    x = qkv.float().cpu()
+    q, k, v = [x[:, i * inner:(i + 1) * inner].view(T, heads, 64).transpose(0, 1) for i in range(3)]
+    ref = (torch.softmax(q @ k.transpose(1, 2) * 0.125, -1) @ v).transpose(0, 1).reshape(T, inner)
+    assert (out.float().cpu() - ref).abs().max() <= 4e-3
