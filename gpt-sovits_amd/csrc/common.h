@@ -118,6 +118,8 @@ struct ConvArgs {
   int bz = 0;                                // batch stride of bias / gate (grouped convs)
 };
 int launch_conv_gemm(int dtype, const ConvArgs& a, hipStream_t s);
+// split-K-in-workgroup streaming GEMM for under-filled grids (gemm_sk.hip): 0 = launched, 1 = not eligible, <0 = error
+int launch_gemm_sk(int dtype, const ConvArgs& a, hipStream_t s);
 // LDS-staged variant for stride-1 convs (conv_lds.hip): 0 = launched, 1 = not eligible, <0 = error
 int launch_conv_lds(int dtype, const ConvArgs& a, hipStream_t s);
 

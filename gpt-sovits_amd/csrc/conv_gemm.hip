@@ -200,6 +200,10 @@ int launch_conv_gemm(int dtype, const ConvArgs& a_in, hipStream_t s) {
   if (a.T_virt == 0) a.T_virt = a.T_out;
   if (a.ups_u > 0 && a.ups_cout == 0) { set_error("conv_gemm: ups_cout missing"); return GSV_ERR_ARG; }
   static const bool no_lds = getenv("GSV_NO_CONV_LDS") != nullptr;   // A/B switch for profiling
+  {
+    const int rc = launch_gemm_sk(dtype, a, s);
+    if (rc <= 0) return rc;
+  }
   if (!no_lds) {
     const int rc = launch_conv_lds(dtype, a, s);
     if (rc <= 0) return rc;

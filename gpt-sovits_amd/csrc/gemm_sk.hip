@@ -1,0 +1,172 @@
+// "Skinny" fp16 GEMM for gfx950: y[t][co] = epilogue(sum_k w[co][k] * x[t][k]) when the output has too few 128 x 128
+// tiles to fill 256 CUs (the DiT's Linear layers at T ~ 1000 frames: 64-192 tiles; prefill / encoder 1x1 layers).
+//
+// There the LDS-tiled kernel (conv_lds.hip) is latency-bound, not MFMA-bound: one workgroup per CU walks 16-32
+// dependent global -> LDS -> barrier -> MFMA steps of ~2 us each.  This kernel is cut the other way:
+//   * 64 x 64 output tile per workgroup (4x as many workgroups), and the K range dealt in 64-wide chunks to the
+//     workgroup's 4 waves (in-workgroup split-K): each wave streams its chunks straight from global memory into MFMA
+//     operand registers -- no LDS, no barrier in the main loop -- with the next chunk's 16 loads in flight under the
+//     current chunk's 16 MFMAs (64 KB in flight per CU);
+//   * k-slot permutation: within a chunk lane (r, h) owns the 64 contiguous bytes k = 32h .. 32h+31 of row r and MFMA j
+//     takes its j-th 16-byte piece from BOTH operands, so every lane load is one aligned 64-byte run and the two lanes
+//     of a row cover one 128-byte line;
+//   * the 4 partial tiles are summed through LDS in a fixed order (deterministic), then bias / gate / residual /
+//     activation are applied and whole channels-last row segments (128 B per 4 threads) are stored.
+#include "common.h"
+
+namespace gsv {
+
+namespace {
+
+__device__ __forceinline__ void mma32(f16v& acc, h8 a, h8 b) { acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0); }
+
+struct Frag { h8 a[2][4], b[2][4]; };
+
+__global__ __launch_bounds__(256) void gemm_sk_f16_kernel(ConvArgs a) {
+  constexpr int LDO = 68;
+  extern __shared__ float os[];                     // [4 waves][64 t][LDO]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const _Float16* __restrict__ x = (const _Float16*)a.x;
+  const _Float16* __restrict__ w = (const _Float16*)a.w;
+  const _Float16* wp[2];
+  const _Float16* xp[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    wp[m] = w + (long long)min(c0 + 32 * m + r, a.Cout - 1) * a.ldw + 32 * h;
+    xp[m] = x + (long long)min(t0 + 32 * m + r, a.T_in - 1) * a.ldx + 32 * h;
+  }
+  f16v acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+  const int nchunks = a.Cin >> 6;
+  auto load = [&](Frag& f, int c) {
+    const int k0 = c << 6;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f.a[m][j] = *(const h8*)(wp[m] + k0 + 8 * j);
+        f.b[m][j] = *(const h8*)(xp[m] + k0 + 8 * j);
+      }
+  };
+  auto compute = [&](const Frag& f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) mma32(acc[m][n], f.a[m][j], f.b[n][j]);
+  };
+  Frag f0, f1;
+  int c = wave;
+  if (c < nchunks) load(f0, c);
+  while (c < nchunks) {
+    if (c + 4 < nchunks) load(f1, c + 4);
+    compute(f0);
+    c += 4;
+    if (c >= nchunks) break;
+    if (c + 4 < nchunks) load(f0, c + 4);
+    compute(f1);
+    c += 4;
+  }
+  // ---- partial tiles -> LDS as [t][co] rows (lane holds column t = 32n + r, rows co = 32m + (i&3) + 8(i>>2) + 4h)
+  float* mine = os + (size_t)wave * 64 * LDO;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f4*)(mine + (size_t)(32 * n + r) * LDO + 32 * m + 8 * q + 4 * h) =
+            (f4){acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+  __syncthreads();
+  // ---- fixed-order sum + epilogue: thread -> row tl = tid / 4, 16 channels at 16 * (tid % 4)
+  const int tl = tid >> 2, cs = (tid & 3) * 16;
+  const int t = t0 + tl;
+  if (t >= a.T_virt || t >= a.T_out) return;
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 16; e += 4) {
+    f4 s4 = *(const f4*)(os + (size_t)tl * LDO + cs + e);
+#pragma unroll
+    for (int ww = 1; ww < 4; ++ww) s4 += *(const f4*)(os + ((size_t)ww * 64 + tl) * LDO + cs + e);
+    v[e] = s4[0]; v[e + 1] = s4[1]; v[e + 2] = s4[2]; v[e + 3] = s4[3];
+  }
+  const int cbase = c0 + cs;
+  const int nv = max(0, min(16, a.Cout - cbase));
+  if (nv == 0) return;
+  const long long yoff = (long long)t * a.ldy + a.y_col0 + cbase;
+  const long long roff = (long long)t * a.ldr + cbase;
+  const bool full = nv == 16;
+  const bool vec_ok = full && ((a.ldy & 7) == 0) && ((a.y_col0 & 7) == 0) && ((a.ldr & 7) == 0);
+  float rr[16];
+  if (a.res) {
+    if (vec_ok && !a.res_f32) {
+      const h8 r0 = *(const h8*)((const _Float16*)a.res + roff), r1 = *(const h8*)((const _Float16*)a.res + roff + 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { rr[e] = (float)r0[e]; rr[8 + e] = (float)r1[e]; }
+    } else {
+      for (int e = 0; e < nv; ++e) rr[e] = a.res_f32 ? ((const float*)a.res)[roff + e] : (float)((const _Float16*)a.res)[roff + e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    if (e >= nv) break;
+    float u = v[e];
+    if (a.bias) u += a.bias[cbase + e];
+    if (a.gate) u *= a.gate[cbase + e];
+    if (a.res) u += rr[e];
+    u *= a.scale;
+    v[e] = post_act_f(a.post_act, u);
+  }
+  if (a.out_f32) {
+    float* yp = (float*)a.y + yoff;
+    if (vec_ok) {
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) *(f4*)(yp + e) = (f4){v[e], v[e + 1], v[e + 2], v[e + 3]};
+    } else {
+      for (int e = 0; e < nv; ++e) yp[e] = v[e];
+    }
+  } else {
+    _Float16* yp = (_Float16*)a.y + yoff;
+    if (vec_ok) {
+      *(h8*)yp = (h8){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+      *(h8*)(yp + 8) = (h8){(_Float16)v[8], (_Float16)v[9], (_Float16)v[10], (_Float16)v[11], (_Float16)v[12], (_Float16)v[13], (_Float16)v[14], (_Float16)v[15]};
+    } else {
+      for (int e = 0; e < nv; ++e) yp[e] = (_Float16)v[e];
+    }
+  }
+}
+
+}  // namespace
+
+// 0 = launched, 1 = not eligible, < 0 error
+int launch_gemm_sk(int dtype, const ConvArgs& a, hipStream_t s) {
+  static const bool off = getenv("GSV_NO_GEMM_SK") != nullptr;     // A/B switch for profiling
+  if (off || dtype != GSV_F16) return 1;
+  if (a.taps != 1 || a.stride != 1 || a.ups_u > 0 || a.accumulate || a.pad != 0 || a.Z != 1 || a.pre_act != ACT_NONE) return 1;
+  if (a.Cin % 64 != 0 || a.Cin < 256 || a.Cout < 64) return 1;
+  if (a.ldx % 8 != 0 || a.ldw % 8 != 0 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return 1;
+  if (a.T_in < a.T_virt) return 1;
+  // only where the 128 x 128 LDS-tiled kernel cannot fill the chip (< 1.5 workgroups per CU)
+  const long long tiles128 = (long long)cdiv(a.T_virt, 128) * cdiv(a.Cout, 128);
+  if (tiles128 >= 384 || a.T_virt < 16) return 1;
+  static bool attr = false;
+  const size_t lds = (size_t)4 * 64 * 68 * 4;
+  if (!attr) {
+    GSV_HIP(hipFuncSetAttribute((const void*)gemm_sk_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  dim3 grid(cdiv(a.T_virt, 64), cdiv(a.Cout, 64));
+  hipLaunchKernelGGL(gemm_sk_f16_kernel, grid, dim3(256), lds, s, a);
+  GSV_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace gsv

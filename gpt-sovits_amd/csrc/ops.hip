@@ -116,7 +116,7 @@ int gsv_op_flash_attn64(const void* qkv, int T, int heads, float scale, void* vt
 
 int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream) {
   gsv::ConvArgs a;
-  a.x = d->x; a.w = d->w; a.bias = d->bias; a.y = d->y; a.res = d->res;
+  a.x = d->x; a.w = d->w; a.bias = d->bias; a.y = d->y; a.res = d->res; a.gate = d->gate;
   a.T_in = d->T_in; a.T_out = d->T_out; a.Cin = d->Cin; a.Cout = d->Cout; a.taps = d->taps;
   a.stride = d->stride; a.dil = d->dil; a.pad = d->pad;
   a.ldx = d->Cin; a.ldw = d->taps * d->Cin;

@@ -48,7 +48,7 @@ class ConvDesc(C.Structure):
                 ("pre_slope", C.c_float), ("post_act", C.c_int), ("scale", C.c_float), ("accumulate", C.c_int),
                 ("out_f32", C.c_int), ("ups_u", C.c_int), ("ups_pad", C.c_int),
                 ("Z", C.c_int), ("xz", C.c_longlong), ("wz", C.c_longlong), ("yz", C.c_longlong),
-                ("ldx", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int)]
+                ("ldx", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int), ("gate", C.c_void_p)]
 
 
 _SIGS = {

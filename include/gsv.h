@@ -230,6 +230,7 @@ typedef struct {
   int ups_u, ups_pad;
   /* optional (0 = defaults): batched GEMM over Z slices with element strides, explicit leading dims */
   int Z; long long xz, wz, yz; int ldx, ldw, ldy;
+  const float* gate;   /* optional per-output-channel gate: y = ((W x + b) * gate + res) * scale */
 } gsv_conv_desc;
 /* fused softmax attention of the DiT blocks alone (fp16, head dim 64): qkv [dev] f16 [T][3*heads*64] (q | k | v column
  * blocks), vt_scratch [dev] heads*64*ceil32(T) halfs, out [dev] f16 [T][heads*64] */

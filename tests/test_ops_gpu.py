@@ -231,3 +231,34 @@ def test_flash_attention_matches_sdpa(T, heads):
     q, k, v = [x[:, i * inner:(i + 1) * inner].view(T, heads, 64).transpose(0, 1) for i in range(3)]
     ref = (torch.softmax(q @ k.transpose(1, 2) * 0.125, -1) @ v).transpose(0, 1).reshape(T, inner)
     assert (out.float().cpu() - ref).abs().max() <= 4e-3
+
+
+@pytest.mark.parametrize("T,K,N,post,use_res,use_gate", [(934, 1024, 3072, 0, False, False), (934, 2048, 1024, 0, True, True),
+                                                          (100, 1024, 2048, 8, False, False), (77, 320, 200, 6, True, False),
+                                                          (16, 256, 64, 0, False, True)])
+def test_skinny_gemm_matches_torch(T, K, N, post, use_res, use_gate):
+    """split-K-in-workgroup streaming GEMM (gemm_sk.hip: Linear layers whose grid cannot fill the chip), fp16 operands,
+    fp32 accumulation, gate / residual / GELU-tanh / SiLU epilogues, ragged T and N: <= 2e-2 relative to the output range."""
+    from gsv import _lib
+    from gsv import synthetic as S
+    _lib.init(0)
+    x = S.hash_symmetric(f"sk_x{T}", (T, K), 1.0, 1).to(DEV, torch.float16)
+    w = (S.hash_symmetric(f"sk_w{N}", (N, K), 1.0, 1) / K ** 0.5 * 3).to(DEV, torch.float16)
+    b = S.hash_symmetric("sk_b", (N,), 0.5, 1).to(DEV)
+    gate = S.hash_symmetric("sk_g", (N,), 1.0, 1).to(DEV) if use_gate else None
+    res = S.hash_symmetric("sk_r", (T, N), 1.0, 1).to(DEV, torch.float16) if use_res else None
+    y = torch.zeros(T, N, device=DEV, dtype=torch.float16)
+    d = _lib.ConvDesc(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), res.data_ptr() if use_res else None, T, T, K, N, 1, 1, 1,
+                      0, 0, 0.0, post, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, gate.data_ptr() if use_gate else None)
+    _lib.check(_lib.lib().gsv_op_conv1d(C.byref(d), 1, None))
+    torch.cuda.synchronize()
+    ref = x.float() @ w.float().t() + b
+    if use_gate:
+        ref = ref * gate
+    if use_res:
+        ref = ref + res.float()
+    if post == 8:
+        ref = F.gelu(ref, approximate="tanh")
+    elif post == 6:
+        ref = F.silu(ref)
+    assert (y.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
