@@ -13,7 +13,13 @@
 // O^T = V^T P^T once V^T's A operand uses the same key <-> k-slot permutation, i.e. two 8-byte loads from the
 // pre-transposed V (vt_kernel below).  The running max / sum / rescale factors of query q then live in the lanes that
 // hold O^T[.][q]: no cross-lane traffic except two xor-shuffles per reduction.
+#include <stdlib.h>
+
 #include "common.h"
+
+// order fence for the software pipelines: the empty asm stops IR-level sinking / hoisting of the loads across it, the
+// sched_barrier stops the machine scheduler
+#define GSV_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 namespace gsv {
 
@@ -35,88 +41,150 @@ __global__ __launch_bounds__(256) void vt_kernel(const _Float16* __restrict__ v,
   }
 }
 
+// QT = 16-query tiles per workgroup.  Every K / V^T fragment a wave loads feeds QT score tiles and QT output tiles:
+// fragment-shaped global loads cost ~120 clocks of the CU's texture-address path each (measured),
+// and with QT = 1 those loads, not MFMA or latency, set the kernel's time.
+template <int QT>
 __global__ __launch_bounds__(256) void flash_attn64_f16_kernel(const _Float16* __restrict__ q, int ldq, const _Float16* __restrict__ k,
                                                                int ldk, const _Float16* __restrict__ vt, int ldv, int T, float scale,
                                                                _Float16* __restrict__ out, int ldo) {
-  constexpr int LDO = 68;
-  __shared__ float Os[4][16][LDO];
-  __shared__ float Ms[4][16], Ls[4][16];
-  const int head = blockIdx.y, q0 = blockIdx.x * 16;
+  constexpr int LDO = 68, BQ = 16 * QT;
+  extern __shared__ float smem[];
+  float* Os = smem;                                  // [4][BQ][LDO]
+  float* Ms = smem + 4 * BQ * LDO;                   // [4][BQ]
+  float* Ls = Ms + 4 * BQ;                           // [4][BQ]
+  // heads are dealt to XCDs in contiguous runs (2 heads per XCD at 16 heads): a head's K / V^T stay in one L2
+  const int vid = xcd_virtual_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int head = vid / gridDim.x, q0 = (vid % gridDim.x) * BQ;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int qrow = min(q0 + r, T - 1);
-  const _Float16* qp = q + (long long)qrow * ldq + head * 64 + g * 8;
-  const h8 qf0 = *(const h8*)qp, qf1 = *(const h8*)(qp + 32);
+  h8 qf0[QT], qf1[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const _Float16* qp = q + (long long)min(q0 + 16 * t + r, T - 1) * ldq + head * 64 + g * 8;
+    qf0[t] = *(const h8*)qp;
+    qf1[t] = *(const h8*)(qp + 32);
+  }
   const _Float16* kh = k + head * 64 + g * 8;
   const _Float16* vh = vt + (long long)head * 64 * ldv + (long long)r * ldv + 4 * g;
-  f4 o[4];
+  f4 o[QT][4];
+  float m[QT], l[QT];
 #pragma unroll
-  for (int d = 0; d < 4; ++d) o[d] = (f4){0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, l = 0.f;
+  for (int t = 0; t < QT; ++t) {
+    m[t] = -INFINITY; l[t] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[t][d] = (f4){0.f, 0.f, 0.f, 0.f};
+  }
   const int nchunks = (T + 31) >> 5;
-  for (int c = wave; c < nchunks; c += 4) {
+  // Two operand sets, used alternately by a loop unrolled by two: with ONE set the prefetched registers have to be
+  // copied into the loop-carried ones at the back edge, and that copy waits for vmcnt(0) -- the prefetch then hides
+  // nothing (seen in the ISA: vmcnt(12) ... vmcnt(0) inside one trip).
+  struct KV { h8 ka0, ka1, kb0, kb1; h4 va[4], vb[4]; };
+  const int lastc = nchunks - 1;
+  auto fetch = [&](KV& f, int c) {
     const int key0 = c << 5;
-    const int ka = min(key0 + r, T - 1), kb = min(key0 + 16 + r, T - 1);
-    const _Float16* pa = kh + (long long)ka * ldk;
-    const _Float16* pb = kh + (long long)kb * ldk;
-    const h8 a0 = *(const h8*)pa, a1 = *(const h8*)(pa + 32), b0 = *(const h8*)pb, b1 = *(const h8*)(pb + 32);
-    h4 va[4], vb[4];
+    const _Float16* pa = kh + (long long)min(key0 + r, T - 1) * ldk;
+    const _Float16* pb = kh + (long long)min(key0 + 16 + r, T - 1) * ldk;
+    f.ka0 = *(const h8*)pa; f.ka1 = *(const h8*)(pa + 32); f.kb0 = *(const h8*)pb; f.kb1 = *(const h8*)(pb + 32);
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const _Float16* pv = vh + (long long)(d * 16) * ldv + key0;
-      va[d] = *(const h4*)pv;
-      vb[d] = *(const h4*)(pv + 16);
+      f.va[d] = *(const h4*)pv;
+      f.vb[d] = *(const h4*)(pv + 16);
     }
-    f4 sa = (f4){0.f, 0.f, 0.f, 0.f}, sb = sa;
-    sa = mma16(a0, qf0, sa); sa = mma16(a1, qf1, sa);
-    sb = mma16(b0, qf0, sb); sb = mma16(b1, qf1, sb);
-    float p[8];
-    float mx = -INFINITY;
+  };
+  auto process = [&](const KV& f, int c, bool valid) {
+    const int key0 = c << 5;
+    h8 av[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      p[i] = (key0 + 4 * g + i < T) ? sa[i] * scale : -INFINITY;
-      p[4 + i] = (key0 + 16 + 4 * g + i < T) ? sb[i] * scale : -INFINITY;
-      mx = fmaxf(mx, fmaxf(p[i], p[4 + i]));
+    for (int d = 0; d < 4; ++d)
+      av[d] = (h8){f.va[d][0], f.va[d][1], f.va[d][2], f.va[d][3], f.vb[d][0], f.vb[d][1], f.vb[d][2], f.vb[d][3]};
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      f4 sa = (f4){0.f, 0.f, 0.f, 0.f}, sb = sa;
+      sa = mma16(f.ka0, qf0[t], sa); sa = mma16(f.ka1, qf1[t], sa);
+      sb = mma16(f.kb0, qf0[t], sb); sb = mma16(f.kb1, qf1[t], sb);
+      float p[8];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        p[i] = (valid && key0 + 4 * g + i < T) ? sa[i] * scale : -INFINITY;
+        p[4 + i] = (valid && key0 + 16 + 4 * g + i < T) ? sb[i] * scale : -INFINITY;
+        mx = fmaxf(mx, fmaxf(p[i], p[4 + i]));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m[t], mx);           // finite: the first chunk of a trip is always valid and has a valid key
+      const float alpha = __expf(m[t] - mnew);
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { p[i] = __expf(p[i] - mnew); ps += p[i]; }
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
+      l[t] = l[t] * alpha + ps;
+      m[t] = mnew;
+      const h8 pf = (h8){(_Float16)p[0], (_Float16)p[1], (_Float16)p[2], (_Float16)p[3], (_Float16)p[4], (_Float16)p[5], (_Float16)p[6], (_Float16)p[7]};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        o[t][d] *= alpha;
+        o[t][d] = mma16(av[d], pf, o[t][d]);        // O^T[d*16 + 4g + i][q = 16t + r]
+      }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mnew = fmaxf(m, mx);              // finite: every chunk holds at least one valid key
-    const float alpha = __expf(m - mnew);
-    float ps = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { p[i] = __expf(p[i] - mnew); ps += p[i]; }
-    ps += __shfl_xor(ps, 16, 64);
-    ps += __shfl_xor(ps, 32, 64);
-    l = l * alpha + ps;
-    m = mnew;
-    const h8 pf = (h8){(_Float16)p[0], (_Float16)p[1], (_Float16)p[2], (_Float16)p[3], (_Float16)p[4], (_Float16)p[5], (_Float16)p[6], (_Float16)p[7]};
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      o[d] *= alpha;
-      const h8 av = (h8){va[d][0], va[d][1], va[d][2], va[d][3], vb[d][0], vb[d][1], vb[d][2], vb[d][3]};
-      o[d] = mma16(av, pf, o[d]);                 // O^T[d*16 + 4g + i][q = r]
-    }
+  };
+  KV fA, fB;
+  fetch(fA, min(wave, lastc));                    // loads are unconditional (index clamped): see gemm_sk.hip
+  for (int c = wave; c < nchunks; c += 8) {
+    fetch(fB, min(c + 4, lastc));
+    GSV_PIN();
+    process(fA, c, true);
+    GSV_PIN();
+    fetch(fA, min(c + 8, lastc));
+    GSV_PIN();
+    process(fB, c + 4, c + 4 < nchunks);         // unconditional (fully masked past the end): a conditional block lets
+                                                 // the compiler sink fB's loads into it, behind process(fA)
+    GSV_PIN();
   }
   // ---- combine the 4 waves' partial (m, l, O)
 #pragma unroll
-  for (int d = 0; d < 4; ++d) *(f4*)&Os[wave][r][d * 16 + 4 * g] = o[d];
-  if (g == 0) { Ms[wave][r] = m; Ls[wave][r] = l; }
-  __syncthreads();
-  const int qq = threadIdx.x >> 4, d4 = (threadIdx.x & 15) * 4;
-  float mt = fmaxf(fmaxf(Ms[0][qq], Ms[1][qq]), fmaxf(Ms[2][qq], Ms[3][qq]));
-  float den = 0.f;
-  f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < QT; ++t) {
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const float e = __expf(Ms[w][qq] - mt);       // exp(-inf) = 0 for a wave that saw no chunk
-    den += e * Ls[w][qq];
-    acc += *(const f4*)&Os[w][qq][d4] * e;
+    for (int d = 0; d < 4; ++d) *(f4*)&Os[((size_t)wave * BQ + 16 * t + r) * LDO + d * 16 + 4 * g] = o[t][d];
+    if (g == 0) { Ms[wave * BQ + 16 * t + r] = m[t]; Ls[wave * BQ + 16 * t + r] = l[t]; }
   }
-  if (q0 + qq < T) {
-    const float inv = 1.f / den;
-    *(h4*)(out + (long long)(q0 + qq) * ldo + head * 64 + d4) =
-        (h4){(_Float16)(acc[0] * inv), (_Float16)(acc[1] * inv), (_Float16)(acc[2] * inv), (_Float16)(acc[3] * inv)};
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int qq = 16 * t + (threadIdx.x >> 4), d4 = (threadIdx.x & 15) * 4;
+    const float mt = fmaxf(fmaxf(Ms[qq], Ms[BQ + qq]), fmaxf(Ms[2 * BQ + qq], Ms[3 * BQ + qq]));
+    float den = 0.f;
+    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float e = __expf(Ms[w * BQ + qq] - mt); // exp(-inf) = 0 for a wave that saw no chunk
+      den += e * Ls[w * BQ + qq];
+      acc += *(const f4*)&Os[((size_t)w * BQ + qq) * LDO + d4] * e;
+    }
+    if (q0 + qq < T) {
+      const float inv = 1.f / den;
+      *(h4*)(out + (long long)(q0 + qq) * ldo + head * 64 + d4) =
+          (h4){(_Float16)(acc[0] * inv), (_Float16)(acc[1] * inv), (_Float16)(acc[2] * inv), (_Float16)(acc[3] * inv)};
+    }
   }
+}
+
+template <int QT>
+static int launch_flash_qt(const void* q, int ldq, const void* k, int ldk, const void* vt_buf, int ldv, int T, int heads, float scale,
+                           void* out, int ldo, hipStream_t s) {
+  const size_t lds = ((size_t)4 * 16 * QT * 68 + 8 * 16 * QT) * 4;
+  static bool attr = false;
+  if (!attr) {
+    GSV_HIP(hipFuncSetAttribute((const void*)flash_attn64_f16_kernel<QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  hipLaunchKernelGGL(flash_attn64_f16_kernel<QT>, dim3(cdiv(T, 16 * QT), heads), dim3(256), lds, s, (const _Float16*)q, ldq,
+                     (const _Float16*)k, ldk, (const _Float16*)vt_buf, ldv, T, scale, (_Float16*)out, ldo);
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
 }
 
 // q / k: [T][ld] with head h at columns h*64..; v likewise; vt_buf: heads * 64 * ceil32(T) halfs of scratch
@@ -127,10 +195,12 @@ int launch_flash_attn64_f16(const void* q, int ldq, const void* k, int ldk, cons
               "flash_attn: operands must be 16-byte aligned with leading dims multiple of 8");
   const int ldv = (T + 31) / 32 * 32;
   hipLaunchKernelGGL(vt_kernel, dim3(ldv / 32, 2, heads), dim3(256), 0, s, (const _Float16*)v, ldvv, T, ldv, (_Float16*)vt_buf);
-  hipLaunchKernelGGL(flash_attn64_f16_kernel, dim3(cdiv(T, 16), heads), dim3(256), 0, s, (const _Float16*)q, ldq, (const _Float16*)k, ldk,
-                     (const _Float16*)vt_buf, ldv, T, scale, (_Float16*)out, ldo);
-  GSV_HIP(hipGetLastError());
-  return GSV_OK;
+  static const int qt_env = getenv("GSV_FLASH_QT") ? atoi(getenv("GSV_FLASH_QT")) : 0;     // A/B switch
+  // more query tiles per workgroup = fewer K / V fragment loads per query, but fewer workgroups: keep >= ~1 per CU
+  int qt = qt_env ? qt_env : ((long long)cdiv(T, 64) * heads >= 200 ? 4 : ((long long)cdiv(T, 32) * heads >= 200 ? 2 : 1));
+  if (qt >= 4) return launch_flash_qt<4>(q, ldq, k, ldk, vt_buf, ldv, T, heads, scale, out, ldo, s);
+  if (qt >= 2) return launch_flash_qt<2>(q, ldq, k, ldk, vt_buf, ldv, T, heads, scale, out, ldo, s);
+  return launch_flash_qt<1>(q, ldq, k, ldk, vt_buf, ldv, T, heads, scale, out, ldo, s);
 }
 
 }  // namespace gsv

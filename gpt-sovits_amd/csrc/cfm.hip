@@ -104,22 +104,44 @@ __global__ void cfm_grn_apply_kernel(T* __restrict__ y, const float* __restrict_
   }
 }
 
-// AdaLN-Zero modulation: y = LN(x) * (1 + scale) + shift, LN without affine, eps 1e-6 (modules.py:275-312).  One wave per row.
-template <typename T>
-__global__ void cfm_ln_mod_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int rows,
-                                  int C, T* __restrict__ y) {
+// AdaLN-Zero modulation: y = LN(x) * (1 + scale) + shift, LN without affine, eps 1e-6 (modules.py:275-312).  One wave per
+// row; the row is read ONCE into registers (three dependent passes over global memory cost 10 us per call at T = 934).
+template <typename T, int NPL>   // NPL = elements per lane, C == 64 * NPL
+__global__ __launch_bounds__(256) void cfm_ln_mod_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int rows, int C, T* __restrict__ y) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const T* xr = x + (long long)row * C;
+  const T* xr = x + (long long)row * C + lane * NPL;
+  float v[NPL];
   float sum = 0.f;
-  for (int c = lane; c < C; c += 64) sum += to_f(xr[c]);
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) { v[i] = to_f(xr[i]); sum += v[i]; }
   const float mean = wave_sum(sum) / (float)C;
   float var = 0.f;
-  for (int c = lane; c < C; c += 64) { float d = to_f(xr[c]) - mean; var += d * d; }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) { const float d = v[i] - mean; var += d * d; }
   const float rstd = rsqrtf(wave_sum(var) / (float)C + 1e-6f);
-  T* yr = y + (long long)row * C;
-  for (int c = lane; c < C; c += 64) yr[c] = (T)((to_f(xr[c]) - mean) * rstd * (1.f + scale[c]) + shift[c]);
+  T* yr = y + (long long)row * C + lane * NPL;
+  const float* sc = scale + lane * NPL;
+  const float* sh = shift + lane * NPL;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) yr[i] = (T)((v[i] - mean) * rstd * (1.f + sc[i]) + sh[i]);
+}
+
+template <typename T>
+int launch_ln_mod(const void* x, const float* scale, const float* shift, int rows, int C, void* y, hipStream_t s) {
+  const dim3 grid(cdiv(rows, 4)), block(256);
+  switch (C / 64) {
+    case 2: hipLaunchKernelGGL((cfm_ln_mod_kernel<T, 2>), grid, block, 0, s, (const T*)x, scale, shift, rows, C, (T*)y); break;
+    case 4: hipLaunchKernelGGL((cfm_ln_mod_kernel<T, 4>), grid, block, 0, s, (const T*)x, scale, shift, rows, C, (T*)y); break;
+    case 8: hipLaunchKernelGGL((cfm_ln_mod_kernel<T, 8>), grid, block, 0, s, (const T*)x, scale, shift, rows, C, (T*)y); break;
+    case 16: hipLaunchKernelGGL((cfm_ln_mod_kernel<T, 16>), grid, block, 0, s, (const T*)x, scale, shift, rows, C, (T*)y); break;
+    case 32: hipLaunchKernelGGL((cfm_ln_mod_kernel<T, 32>), grid, block, 0, s, (const T*)x, scale, shift, rows, C, (T*)y); break;
+    default: set_error("cfm: dim %d is not one of 128, 256, 512, 1024, 2048", C); return GSV_ERR_ARG;
+  }
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
 }
 
 // rotary embedding on the first 2*half channels of the q and k projections (x_transformers' apply_rotary_pos_emb on the
@@ -349,7 +371,7 @@ int cfm_infer_one(gsv_cfm* c, hipStream_t s, const float* mods, const float* mu,
     for (int l = 0; l < g.depth; ++l) {
       const DitBlockW& b = c->blocks[l];
       const float* m = mods + ((size_t)l * N + step) * 6 * D;   // shift_a, scale_a, gate_a, shift_m, scale_m, gate_m
-      hipLaunchKernelGGL(cfm_ln_mod_kernel<T>, dim3(cdiv(Tn, 4)), dim3(256), 0, s, (const T*)hb, m + D, m, Tn, D, (T*)nrm);
+      GSV_RC(launch_ln_mod<T>(hb, m + D, m, Tn, D, nrm, s));
       GSV_RC(conv(h, s, b.qkv, nrm, D, Tn, qkv, Tn, o));
       CFM_LAUNCH(cfm_rope_kernel<T>, Tn * half * 2, (T*)qkv, 3 * inner, inner, Tn, half, cs);
       if (h->dtype == GSV_F16 && g.dim_head == 64 && !c->materialized_attn) {
@@ -363,7 +385,7 @@ int cfm_infer_one(gsv_cfm* c, hipStream_t s, const float* mods, const float* mu,
       }
       ConvOpt og; og.gate = m + 2 * D; og.res = hb;
       GSV_RC(conv(h, s, b.out, ao, inner, Tn, hb, Tn, og));
-      hipLaunchKernelGGL(cfm_ln_mod_kernel<T>, dim3(cdiv(Tn, 4)), dim3(256), 0, s, (const T*)hb, m + 4 * D, m + 3 * D, Tn, D, (T*)nrm);
+      GSV_RC(launch_ln_mod<T>(hb, m + 4 * D, m + 3 * D, Tn, D, nrm, s));
       ConvOpt of; of.post_act = ACT_GELU_TANH;
       GSV_RC(conv(h, s, b.ff1, nrm, D, Tn, ff, Tn, of));
       ConvOpt o2; o2.gate = m + 5 * D; o2.res = hb;
@@ -371,7 +393,7 @@ int cfm_infer_one(gsv_cfm* c, hipStream_t s, const float* mods, const float* mu,
     }
     // ---- AdaLayerNormZero_Final (scale, shift) + proj_out, then the Euler step (models.py:1080-1084)
     const float* mf = mods + (size_t)g.depth * N * 6 * D + (size_t)step * 2 * D;
-    hipLaunchKernelGGL(cfm_ln_mod_kernel<T>, dim3(cdiv(Tn, 4)), dim3(256), 0, s, (const T*)hb, mf, mf + D, Tn, D, (T*)nrm);
+    GSV_RC(launch_ln_mod<T>(hb, mf, mf + D, Tn, D, nrm, s));
     ConvOpt ov; ov.out_f32 = 1;
     GSV_RC(conv(h, s, c->proj_out, nrm, D, Tn, v, Tn, ov));
     CFM_LAUNCH(cfm_euler_kernel<T>, (long long)Tn * md, x, (const float*)v, d, Tn, Tp, md, (T*)xin, ldin);
@@ -388,6 +410,8 @@ int gsv_cfm_create(const gsv_dit_config* cfg, int dtype, gsv_cfm_t** out) {
   GSV_REQUIRE(cfg && out, "cfm_create: null argument");
   GSV_REQUIRE(dtype == GSV_F16 || dtype == GSV_F32, "cfm_create: bad dtype");
   GSV_REQUIRE(cfg->dim > 0 && cfg->dim % 16 == 0 && (cfg->dim / 16) % 8 == 0, "cfm_create: dim=%d must be a multiple of 128", cfg->dim);
+  GSV_REQUIRE(cfg->dim == 128 || cfg->dim == 256 || cfg->dim == 512 || cfg->dim == 1024 || cfg->dim == 2048,
+              "cfm_create: dim=%d must be 128, 256, 512, 1024 or 2048 (row-in-registers LayerNorm)", cfg->dim);
   GSV_REQUIRE(cfg->dim_head % 16 == 0 && cfg->heads > 0 && cfg->depth > 0, "cfm_create: bad head configuration");
   GSV_REQUIRE(cfg->text_dim % 8 == 0 && cfg->mel_dim % 4 == 0 && cfg->ff_mult > 0 && cfg->conv_layers >= 0, "cfm_create: bad dims");
   int n = 0;

@@ -62,6 +62,14 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// XCD-aware workgroup order: the dispatcher deals linear workgroup ids round-robin to the 8 XCDs (id % 8), each with its
+// own 4 MB L2.  This bijection gives XCD x the CONTIGUOUS run of virtual ids [x * n/8, (x+1) * n/8), so a kernel that
+// decodes (tile row, tile column) from the virtual id keeps each XCD on its own slice of the weights / heads.
+__device__ __forceinline__ int xcd_virtual_id(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
 static inline size_t dt_size(int dt) { return dt == GSV_F16 ? 2 : 4; }
 
 // ------------------------------------------------------------------------------------

@@ -184,6 +184,10 @@ template <typename T> static int launch_t(const ConvArgs& a, hipStream_t s) {
   if (a.Cout <= 32) {
     dim3 grid(cdiv(a.T_virt, 512), cdiv(a.Cout, 32), a.Z);
     hipLaunchKernelGGL((conv_gemm_kernel<T, 1, 4, 1, 4>), grid, dim3(256), 0, s, a);
+  } else if (a.Cout <= 64 && (long long)cdiv(a.T_virt, 256) * a.Z < 192) {
+    // under-filled grid (e.g. the DiT's grouped position conv: 16 groups x 4 time tiles): 64 x 64 tiles instead
+    dim3 grid(cdiv(a.T_virt, 64), cdiv(a.Cout, 64), a.Z);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 1, 1, 2, 2>), grid, dim3(256), 0, s, a);
   } else if (a.Cout <= 64) {
     dim3 grid(cdiv(a.T_virt, 256), cdiv(a.Cout, 64), a.Z);
     hipLaunchKernelGGL((conv_gemm_kernel<T, 2, 2, 1, 4>), grid, dim3(256), 0, s, a);

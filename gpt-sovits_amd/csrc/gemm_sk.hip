@@ -14,6 +14,10 @@
 //     activation are applied and whole channels-last row segments (128 B per 4 threads) are stored.
 #include "common.h"
 
+// order fence for the software pipelines: the empty asm stops IR-level sinking / hoisting of the loads across it, the
+// sched_barrier stops the machine scheduler
+#define GSV_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
 namespace gsv {
 
 namespace {
@@ -27,7 +31,9 @@ __global__ __launch_bounds__(256) void gemm_sk_f16_kernel(ConvArgs a) {
   extern __shared__ float os[];                     // [4 waves][64 t][LDO]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  // each XCD takes a contiguous band of output-channel tiles: its L2 holds 1/8 of the weights plus the activations
+  const int vid = xcd_virtual_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int t0 = (vid % gridDim.x) * 64, c0 = (vid / gridDim.x) * 64;
   const _Float16* __restrict__ x = (const _Float16*)a.x;
   const _Float16* __restrict__ w = (const _Float16*)a.w;
   const _Float16* wp[2];
@@ -63,17 +69,23 @@ __global__ __launch_bounds__(256) void gemm_sk_f16_kernel(ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) mma32(acc[m][n], f.a[m][j], f.b[n][j]);
   };
+  // Prefetch rules learned from the ISA: (1) loads are UNCONDITIONAL (chunk index clamped, a
+  // spare tail load is harmless) -- a load under a runtime condition makes the compiler branch around it and drain
+  // vmcnt(0) at the join; (2) two register sets used alternately by a loop unrolled by two -- with one set the
+  // back-edge copy waits for vmcnt(0); (3) sched_barrier pins each 16-MFMA block behind the OTHER set's 16 loads, so
+  // the waits are counted (vmcnt(16)) and a whole chunk is in flight under the MFMAs.
   Frag f0, f1;
-  int c = wave;
-  if (c < nchunks) load(f0, c);
-  while (c < nchunks) {
-    if (c + 4 < nchunks) load(f1, c + 4);
+  const int last = nchunks - 1;
+  load(f0, min(wave, last));
+  for (int c = wave; c < nchunks; c += 8) {
+    load(f1, min(c + 4, last));
+    GSV_PIN();
     compute(f0);
-    c += 4;
-    if (c >= nchunks) break;
-    if (c + 4 < nchunks) load(f0, c + 4);
-    compute(f1);
-    c += 4;
+    GSV_PIN();
+    load(f0, min(c + 8, last));
+    GSV_PIN();
+    if (c + 4 < nchunks) compute(f1);
+    GSV_PIN();
   }
   // ---- partial tiles -> LDS as [t][co] rows (lane holds column t = 32n + r, rows co = 32m + (i&3) + 8(i>>2) + 4h)
   float* mine = os + (size_t)wave * 64 * LDO;
@@ -156,7 +168,7 @@ int launch_gemm_sk(int dtype, const ConvArgs& a, hipStream_t s) {
   if (a.T_in < a.T_virt) return 1;
   // only where the 128 x 128 LDS-tiled kernel cannot fill the chip (< 1.5 workgroups per CU)
   const long long tiles128 = (long long)cdiv(a.T_virt, 128) * cdiv(a.Cout, 128);
-  if (tiles128 >= 384 || a.T_virt < 16) return 1;
+  if (tiles128 >= 384) return 1;
   static bool attr = false;
   const size_t lds = (size_t)4 * 64 * 68 * 4;
   if (!attr) {
