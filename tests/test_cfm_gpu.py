@@ -98,3 +98,35 @@ def test_decode_encp_matches_reference(name):
     assert np.sqrt(((f16 - g) ** 2).mean()) <= 0.02 * np.sqrt((g ** 2).mean())
     with pytest.raises(NotImplementedError):
         m.decode(codes.to(DEV), text.to(DEV), refer.to(DEV))
+
+
+@pytest.mark.parametrize("B,T,Tp", [(1, 1, 0), (1, 5, 5), (2, 37, 0), (3, 20, 7)])
+def test_cfm_edge_shapes_match_oracle(B, T, Tp):
+    """single frame, prompt covering the whole sequence (nothing generated: all zeros), no prompt at all, and a batch
+    whose ONE prompt is broadcast over the rows (as using_vocoder_synthesis_batched_infer passes it): fp32 engine vs the
+    oracle, max-abs <= 2e-3."""
+    from gsv import synthetic as S
+    from oracle import cfm_oracle
+    cfg = S.small_dit_config()
+    sd = S.make_dit_state_dict(cfg, seed=5)
+    mu = S.hash_symmetric("edge_mu", (B, T, cfg["text_dim"]), 1.0, B * 100 + T)
+    prompt = S.hash_symmetric("edge_prompt", (1, cfg["mel_dim"], Tp), 1.0, T)
+    noise = S.hash_normal("edge_noise", (B, cfg["mel_dim"], T), T)
+    out = _cfm(cfg, sd, torch.float32).inference(mu.to(DEV), None, prompt.to(DEV), 3, noise=noise).cpu()
+    ref = cfm_oracle.cfm_inference(sd, cfg, mu, prompt.expand(B, -1, -1), 3, noise.clone())
+    assert out.shape == ref.shape == (B, cfg["mel_dim"], T)
+    assert (out - ref).abs().max() <= 2e-3
+    if Tp == T:
+        assert float(out.abs().max()) == 0.0
+
+
+def test_decode_encp_single_token():
+    """one semantic token, one phoneme (2 enc_p frames -> 3 feature frames for v3): fp32 engine vs the oracle <= 5e-4."""
+    from oracle.vits_oracle import VitsOracle
+    case = dict(cases.ENCP_CASES["encp_small_v3"], T=1, L=1)
+    cfg, sd, codes, text, refer = cases.encp_case_inputs(case)
+    m = _v3(cfg, sd, "v3", torch.float32)
+    fea, _ = m.decode_encp(codes.to(DEV), text.to(DEV), refer.to(DEV))
+    ref, _ = VitsOracle(sd, cfg).decode_encp(codes, text, refer, speed=1, version="v3")
+    assert tuple(fea.shape) == tuple(ref.shape) == (1, 512, 3)
+    assert (fea.cpu() - ref).abs().max() <= 5e-4
