@@ -24,6 +24,54 @@ namespace {
 
 __device__ __forceinline__ void mma32(f16v& acc, h8 a, h8 b) { acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0); }
 
+// bias / gate / residual / scale / activation on 16 consecutive output channels of row t, stored as two 16-byte pieces
+__device__ __forceinline__ void row_epilogue(const ConvArgs& a, float (&v)[16], int t, int cbase_in) {
+  const int cbase = cbase_in;
+  const int nv = max(0, min(16, a.Cout - cbase));
+  if (nv == 0) return;
+  const long long yoff = (long long)t * a.ldy + a.y_col0 + cbase;
+  const long long roff = (long long)t * a.ldr + cbase;
+  const bool full = nv == 16;
+  const bool vec_ok = full && ((a.ldy & 7) == 0) && ((a.y_col0 & 7) == 0) && ((a.ldr & 7) == 0);
+  float rr[16];
+  if (a.res) {
+    if (vec_ok && !a.res_f32) {
+      const h8 r0 = *(const h8*)((const _Float16*)a.res + roff), r1 = *(const h8*)((const _Float16*)a.res + roff + 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { rr[e] = (float)r0[e]; rr[8 + e] = (float)r1[e]; }
+    } else {
+      for (int e = 0; e < nv; ++e) rr[e] = a.res_f32 ? ((const float*)a.res)[roff + e] : (float)((const _Float16*)a.res)[roff + e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    if (e >= nv) break;
+    float u = v[e];
+    if (a.bias) u += a.bias[cbase + e];
+    if (a.gate) u *= a.gate[cbase + e];
+    if (a.res) u += rr[e];
+    u *= a.scale;
+    v[e] = post_act_f(a.post_act, u);
+  }
+  if (a.out_f32) {
+    float* yp = (float*)a.y + yoff;
+    if (vec_ok) {
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) *(f4*)(yp + e) = (f4){v[e], v[e + 1], v[e + 2], v[e + 3]};
+    } else {
+      for (int e = 0; e < nv; ++e) yp[e] = v[e];
+    }
+  } else {
+    _Float16* yp = (_Float16*)a.y + yoff;
+    if (vec_ok) {
+      *(h8*)yp = (h8){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+      *(h8*)(yp + 8) = (h8){(_Float16)v[8], (_Float16)v[9], (_Float16)v[10], (_Float16)v[11], (_Float16)v[12], (_Float16)v[13], (_Float16)v[14], (_Float16)v[15]};
+    } else {
+      for (int e = 0; e < nv; ++e) yp[e] = (_Float16)v[e];
+    }
+  }
+}
+
 struct Frag { h8 a[2][4], b[2][4]; };
 
 __global__ __launch_bounds__(256) void gemm_sk_f16_kernel(ConvArgs a) {
@@ -110,50 +158,104 @@ __global__ __launch_bounds__(256) void gemm_sk_f16_kernel(ConvArgs a) {
     for (int ww = 1; ww < 4; ++ww) s4 += *(const f4*)(os + ((size_t)ww * 64 + tl) * LDO + cs + e);
     v[e] = s4[0]; v[e + 1] = s4[1]; v[e + 2] = s4[2]; v[e + 3] = s4[3];
   }
-  const int cbase = c0 + cs;
-  const int nv = max(0, min(16, a.Cout - cbase));
-  if (nv == 0) return;
-  const long long yoff = (long long)t * a.ldy + a.y_col0 + cbase;
-  const long long roff = (long long)t * a.ldr + cbase;
-  const bool full = nv == 16;
-  const bool vec_ok = full && ((a.ldy & 7) == 0) && ((a.y_col0 & 7) == 0) && ((a.ldr & 7) == 0);
-  float rr[16];
-  if (a.res) {
-    if (vec_ok && !a.res_f32) {
-      const h8 r0 = *(const h8*)((const _Float16*)a.res + roff), r1 = *(const h8*)((const _Float16*)a.res + roff + 8);
+  row_epilogue(a, v, t, c0 + cs);
+}
+
+
+// ---- variant B: 64 x 64 tile, the 4 waves own 32 x 32 quadrants over the FULL K, operands shared through LDS.
+// 8x fewer cache lines touched per flop than the streaming kernel above (whole 512-byte row segments, each fragment
+// read by two waves from LDS), and the latency of a dependent global -> LDS -> MFMA step is amortised over a 256-wide K
+// slab (64 KB per step, two register sets + two LDS buffers = the next TWO slabs in flight under the current one).
+struct Slab { h8 a[8], b[8]; };
+
+__global__ __launch_bounds__(256) void gemm_t64_f16_kernel(ConvArgs a) {
+  constexpr int LDO = 68;
+  extern __shared__ float os[];                     // 2 x [A: 64 rows x 512 B][B: 64 rows x 512 B]; epilogue: [64 t][LDO] fp32
+  char* lds = (char*)os;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int vid = xcd_virtual_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int t0 = (vid % gridDim.x) * 64, c0 = (vid / gridDim.x) * 64;
+  const _Float16* __restrict__ x = (const _Float16*)a.x;
+  const _Float16* __restrict__ w = (const _Float16*)a.w;
+  // staging: thread -> 16-byte piece (tid & 31) of rows (tid >> 5) + 8 i; LDS slot = piece ^ (row & 15) (conflict-free
+  // fragment reads for 16 consecutive rows, conflict-free lane-contiguous writes)
+  const int sp = tid & 31, sr = tid >> 5;
+  const _Float16* wp[8];
+  const _Float16* xp[8];
+  int woff[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { rr[e] = (float)r0[e]; rr[8 + e] = (float)r1[e]; }
-    } else {
-      for (int e = 0; e < nv; ++e) rr[e] = a.res_f32 ? ((const float*)a.res)[roff + e] : (float)((const _Float16*)a.res)[roff + e];
-    }
+  for (int i = 0; i < 8; ++i) {
+    const int row = 8 * i + sr;
+    wp[i] = w + (long long)min(c0 + row, a.Cout - 1) * a.ldw + 8 * sp;
+    xp[i] = x + (long long)min(t0 + row, a.T_in - 1) * a.ldx + 8 * sp;
+    woff[i] = row * 512 + ((sp ^ (row & 15)) << 4);
   }
+  auto load = [&](Slab& f, int c) {
+    const int k0 = c << 8;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    if (e >= nv) break;
-    float u = v[e];
-    if (a.bias) u += a.bias[cbase + e];
-    if (a.gate) u *= a.gate[cbase + e];
-    if (a.res) u += rr[e];
-    u *= a.scale;
-    v[e] = post_act_f(a.post_act, u);
-  }
-  if (a.out_f32) {
-    float* yp = (float*)a.y + yoff;
-    if (vec_ok) {
+    for (int i = 0; i < 8; ++i) { f.a[i] = *(const h8*)(wp[i] + k0); f.b[i] = *(const h8*)(xp[i] + k0); }
+  };
+  auto stage = [&](const Slab& f, int buf) {
+    char* base = lds + buf * 65536;
 #pragma unroll
-      for (int e = 0; e < 16; e += 4) *(f4*)(yp + e) = (f4){v[e], v[e + 1], v[e + 2], v[e + 3]};
-    } else {
-      for (int e = 0; e < nv; ++e) yp[e] = v[e];
+    for (int i = 0; i < 8; ++i) { *(h8*)(base + woff[i]) = f.a[i]; *(h8*)(base + 32768 + woff[i]) = f.b[i]; }
+  };
+  f16v acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  const int rowA = wm * 32 + r, rowB = wn * 32 + r;
+  auto compute = [&](int buf) {
+    const char* pa = lds + buf * 65536 + rowA * 512;
+    const char* pb = lds + buf * 65536 + 32768 + rowB * 512;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+      const h8 fa0 = *(const h8*)(pa + ((((2 * j + h)) ^ (rowA & 15)) << 4));
+      const h8 fb0 = *(const h8*)(pb + ((((2 * j + h)) ^ (rowB & 15)) << 4));
+      const h8 fa1 = *(const h8*)(pa + ((((2 * j + 2 + h)) ^ (rowA & 15)) << 4));
+      const h8 fb1 = *(const h8*)(pb + ((((2 * j + 2 + h)) ^ (rowB & 15)) << 4));
+      mma32(acc0, fa0, fb0);
+      mma32(acc1, fa1, fb1);
     }
-  } else {
-    _Float16* yp = (_Float16*)a.y + yoff;
-    if (vec_ok) {
-      *(h8*)yp = (h8){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
-      *(h8*)(yp + 8) = (h8){(_Float16)v[8], (_Float16)v[9], (_Float16)v[10], (_Float16)v[11], (_Float16)v[12], (_Float16)v[13], (_Float16)v[14], (_Float16)v[15]};
-    } else {
-      for (int e = 0; e < nv; ++e) yp[e] = (_Float16)v[e];
-    }
+  };
+  const int nslab = a.Cin >> 8, last = nslab - 1;    // even (Cin % 512 == 0, checked by the launcher)
+  Slab s0, s1;
+  load(s0, 0);
+  load(s1, min(1, last));
+  for (int c = 0; c < nslab; c += 2) {
+    stage(s0, 0);
+    GSV_PIN();
+    load(s0, min(c + 2, last));
+    GSV_PIN();
+    __syncthreads();
+    compute(0);
+    GSV_PIN();
+    stage(s1, 1);
+    GSV_PIN();
+    load(s1, min(c + 3, last));
+    GSV_PIN();
+    __syncthreads();
+    compute(1);
+    GSV_PIN();
   }
+  __syncthreads();
+  // ---- quadrant -> LDS as [t][co] rows, then the same row-segment epilogue as the streaming kernel
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *(f4*)(os + (size_t)(32 * wn + r) * LDO + 32 * wm + 8 * q + 4 * h) =
+        (f4){acc0[4 * q] + acc1[4 * q], acc0[4 * q + 1] + acc1[4 * q + 1], acc0[4 * q + 2] + acc1[4 * q + 2], acc0[4 * q + 3] + acc1[4 * q + 3]};
+  __syncthreads();
+  const int tl = tid >> 2, cs = (tid & 3) * 16;
+  const int t = t0 + tl;
+  if (t >= a.T_virt || t >= a.T_out) return;
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 16; e += 4) {
+    const f4 s4 = *(const f4*)(os + (size_t)tl * LDO + cs + e);
+    v[e] = s4[0]; v[e + 1] = s4[1]; v[e + 2] = s4[2]; v[e + 3] = s4[3];
+  }
+  row_epilogue(a, v, t, c0 + cs);
 }
 
 }  // namespace
@@ -169,6 +271,19 @@ int launch_gemm_sk(int dtype, const ConvArgs& a, hipStream_t s) {
   // only where the 128 x 128 LDS-tiled kernel cannot fill the chip (< 1.5 workgroups per CU)
   const long long tiles128 = (long long)cdiv(a.T_virt, 128) * cdiv(a.Cout, 128);
   if (tiles128 >= 384) return 1;
+  static const bool t64 = !(getenv("GSV_GEMM_T64") && getenv("GSV_GEMM_T64")[0] == '0');   // A/B switch
+  if (t64 && a.Cin % 512 == 0) {
+    static bool attr64 = false;
+    const size_t lds64 = 131072;
+    if (!attr64) {
+      GSV_HIP(hipFuncSetAttribute((const void*)gemm_t64_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
+      attr64 = true;
+    }
+    dim3 grid64(cdiv(a.T_virt, 64), cdiv(a.Cout, 64));
+    hipLaunchKernelGGL(gemm_t64_f16_kernel, grid64, dim3(256), lds64, s, a);
+    GSV_HIP(hipGetLastError());
+    return 0;
+  }
   static bool attr = false;
   const size_t lds = (size_t)4 * 64 * 68 * 4;
   if (!attr) {
