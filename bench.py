@@ -93,8 +93,8 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--tokens", type=int, default=100)
     ap.add_argument("--cpu-utts", type=int, default=2)
@@ -160,6 +160,9 @@ def main():
         out = step()
         torch.cuda.synchronize()
         times.append(time.perf_counter() - ts)
+        if rank == 0:
+            log("step %d: %.1f ms, stages (text, to_batch, AR, SoVITS) = %s" % (len(times) - 1, 1e3 * times[-1],
+                ", ".join("%.1f" % (1e3 * v) for v in tts.last_timing)))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -211,6 +214,7 @@ def main():
                                    "random-init v2 weights", "utterances_per_gpu": B, "tokens_per_utterance": TOK,
                        "parallelism": f"utterance-sharded x{world}"},
             "p50_utterance_latency_ms": round(1e3 * statistics.median(times), 2),
+            "step_ms": [round(1e3 * t, 1) for t in times],
             "p50_single_utterance_latency_ms": round(1e3 * lat_b1, 2),
             "rtf": round(elapsed / audio_s, 6),
             "stage_ms_last_step": {"to_batch": round(1e3 * t_batch, 2), "ar_t34": round(1e3 * t_ar, 2),

@@ -142,6 +142,146 @@ __global__ void prefill_attn_kernel(const T* __restrict__ qkv, const T* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Prefill attention on MFMA (fp16, head dim 32), same construction as the DiT kernel (attn.hip): transposed scores
+// S^T = K Q^T (one 16x16x32 MFMA per 16 keys x 16 queries: k = head dim), the probabilities a lane holds are the B
+// operand of O^T = V^T P^T, keys dealt in 32-key chunks to the 4 waves with online softmax, LDS combine.  K comes
+// straight from the head-major cache (a 16-key fragment is 1 KB contiguous), V^T from a per-prefill scratch.
+// Mask (t2s_model.py:655-683): text queries see the text keys; audio queries see all text + causal audio.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prefill_vt_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ row_off,
+                                                         const int* __restrict__ x_len, int P, int d, int H, int spad,
+                                                         _Float16* __restrict__ vt) {
+  __shared__ _Float16 tile[32][34];
+  const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * 32;
+  const int S = x_len[b] + P;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int j = j0 + i;
+    tile[i][tx] = j < S ? qkv[(long long)(row_off[b] + j) * 3 * d + 2 * d + h * 32 + tx] : (_Float16)0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) vt[(((long long)b * H + h) * 32 + i) * spad + j0 + tx] = tile[tx][i];
+}
+
+template <int QT>
+__global__ __launch_bounds__(256) void prefill_flash32_f16_kernel(const _Float16* __restrict__ qkv, const _Float16* __restrict__ kc,
+                                                                   const _Float16* __restrict__ vt, const int* __restrict__ row_off,
+                                                                   const int* __restrict__ x_len, int P, int d, int H, int smax,
+                                                                   int spad, _Float16* __restrict__ out) {
+  constexpr int BQ = 16 * QT, LDO = 36;
+  __shared__ float Os[4][BQ][LDO];
+  __shared__ float Ms[4][BQ], Ls[4][BQ];
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQ;
+  const int X = x_len[b], S = X + P;
+  if (q0 >= S) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const float scale = rsqrtf(32.f);
+  h8 qf[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+    qf[t] = *(const h8*)(qkv + (long long)(row_off[b] + min(q0 + 16 * t + r, S - 1)) * 3 * d + h * 32 + g * 8);
+  const _Float16* kb = kc + ((long long)b * H + h) * smax * 32 + g * 8;
+  const _Float16* vb = vt + (((long long)b * H + h) * 32 + r) * spad + 4 * g;
+  f4 o[QT][2];
+  float m[QT], l[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) { m[t] = -INFINITY; l[t] = 0.f; o[t][0] = (f4){0.f, 0.f, 0.f, 0.f}; o[t][1] = o[t][0]; }
+  const int qlast = min(q0 + BQ, S) - 1;
+  const int nk = qlast < X ? X : qlast + 1;          // workgroup-uniform bound of the key range
+  const int nchunks = (nk + 31) >> 5, lastc = nchunks - 1;
+  struct KV { h8 ka, kb2; h4 va[2], vb2[2]; };
+  auto fetch = [&](KV& f, int c) {
+    const int key0 = c << 5;
+    f.ka = *(const h8*)(kb + (long long)min(key0 + r, S - 1) * 32);
+    f.kb2 = *(const h8*)(kb + (long long)min(key0 + 16 + r, S - 1) * 32);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      f.va[dt] = *(const h4*)(vb + (long long)(dt * 16) * spad + key0);
+      f.vb2[dt] = *(const h4*)(vb + (long long)(dt * 16) * spad + key0 + 16);
+    }
+  };
+  auto process = [&](const KV& f, int c, bool valid) {
+    const int key0 = c << 5;
+    h8 av[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+      av[dt] = (h8){f.va[dt][0], f.va[dt][1], f.va[dt][2], f.va[dt][3], f.vb2[dt][0], f.vb2[dt][1], f.vb2[dt][2], f.vb2[dt][3]};
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const int qi = q0 + 16 * t + r;
+      const int lim = qi < X ? X : qi + 1;           // keys [0, lim) are visible to query qi
+      f4 sa = (f4){0.f, 0.f, 0.f, 0.f}, sb = sa;
+      sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ka, qf[t], sa, 0, 0, 0);
+      sb = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.kb2, qf[t], sb, 0, 0, 0);
+      float p[8];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        p[i] = (valid && key0 + 4 * g + i < lim) ? sa[i] * scale : -INFINITY;
+        p[4 + i] = (valid && key0 + 16 + 4 * g + i < lim) ? sb[i] * scale : -INFINITY;
+        mx = fmaxf(mx, fmaxf(p[i], p[4 + i]));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m[t], mx);
+      const float ms = mnew == -INFINITY ? 0.f : mnew;   // a causal query may see none of this wave's keys yet
+      const float alpha = __expf(m[t] - ms);
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { p[i] = __expf(p[i] - ms); ps += p[i]; }
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
+      l[t] = l[t] * alpha + ps;
+      m[t] = mnew;
+      const h8 pf = (h8){(_Float16)p[0], (_Float16)p[1], (_Float16)p[2], (_Float16)p[3], (_Float16)p[4], (_Float16)p[5], (_Float16)p[6], (_Float16)p[7]};
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        o[t][dt] *= alpha;
+        o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[dt], pf, o[t][dt], 0, 0, 0);
+      }
+    }
+  };
+#define GSV_PIN2() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  KV fA, fB;
+  fetch(fA, min(wave, lastc));
+  for (int c = wave; c < nchunks; c += 8) {
+    fetch(fB, min(c + 4, lastc));
+    GSV_PIN2();
+    process(fA, c, true);
+    GSV_PIN2();
+    fetch(fA, min(c + 8, lastc));
+    GSV_PIN2();
+    process(fB, c + 4, c + 4 < nchunks);
+    GSV_PIN2();
+  }
+#undef GSV_PIN2
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) *(f4*)&Os[wave][16 * t + r][dt * 16 + 4 * g] = o[t][dt];
+    if (g == 0) { Ms[wave][16 * t + r] = m[t]; Ls[wave][16 * t + r] = l[t]; }
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < BQ * 8; it += 256) {
+    const int qq = it >> 3, d4 = (it & 7) * 4;
+    if (q0 + qq >= S) continue;
+    const float mt = fmaxf(fmaxf(Ms[0][qq], Ms[1][qq]), fmaxf(Ms[2][qq], Ms[3][qq]));   // finite: key 0 is visible to every query
+    float den = 0.f;
+    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float e = __expf(Ms[w][qq] - mt);
+      den += e * Ls[w][qq];
+      acc += *(const f4*)&Os[w][qq][d4] * e;
+    }
+    const float inv = 1.f / den;
+    *(h4*)(out + (long long)(row_off[b] + q0 + qq) * d + h * 32 + d4) =
+        (h4){(_Float16)(acc[0] * inv), (_Float16)(acc[1] * inv), (_Float16)(acc[2] * inv), (_Float16)(acc[3] * inv)};
+  }
+}
+
 // gather each row's last prefill position of the fp32 pre-LN2 stream into the decode buffer
 __global__ void gather_last_kernel(const float* __restrict__ y2, const int* __restrict__ row_off,
                                    const int* __restrict__ x_len, int P, int d, float* __restrict__ ybuf) {
@@ -984,6 +1124,7 @@ struct gsv_t2s {
   // prefill workspace (grown on demand)
   size_t pf_rows = 0;
   void *pf_x = nullptr, *pf_qkv = nullptr, *pf_attn = nullptr, *pf_h = nullptr;
+  void* pf_vt = nullptr; size_t pf_vt_cap = 0;   // V^T scratch of the MFMA prefill attention: [B][H][32][ceil32(maxS)] halfs
   float *pf_y = nullptr, *pf_bert = nullptr;
   void* pf_bert_t = nullptr;
   // current batch
@@ -1352,6 +1493,10 @@ int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_le
     maxS = S > maxS ? S : maxS;
   }
   GSV_RC(grow_prefill(h, M, SX));
+  if (h->dtype == GSV_F16) {
+    const size_t need_vt = (size_t)B * H * 32 * ((maxS + 31) / 32 * 32) * 2;
+    if (need_vt > h->pf_vt_cap) { GSV_RC(dev_alloc(h, &h->pf_vt, need_vt + need_vt / 4)); h->pf_vt_cap = need_vt + need_vt / 4; }
+  }
   h->B = B; h->P = P;
   GSV_HIP(hipMemcpyAsync(h->d_x_len, phone_lens, B * 4, hipMemcpyHostToDevice, s));
   GSV_HIP(hipMemcpyAsync(h->d_row_off, row_off.data(), B * 4, hipMemcpyHostToDevice, s));
@@ -1379,6 +1524,7 @@ int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_le
 #undef GSV_EMBED
   GSV_HIP(hipGetLastError());
 
+  static const bool scalar_pf = getenv("GSV_SCALAR_PREFILL_ATTN") != nullptr;   // A/B switch: thread-per-query VALU kernel
   for (int li = 0; li < c.n_layer; ++li) {
     const LayerW& L = h->layers[li];
     ConvArgs g;
@@ -1388,6 +1534,14 @@ int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_le
     if (h->dtype == GSV_F16) {
       hipLaunchKernelGGL(kv_scatter_kernel<_Float16>, dim3(maxS, B), dim3(128), 0, s, (const _Float16*)h->pf_qkv,
                          h->d_row_off, h->d_x_len, P, d, H, h->max_seq, (_Float16*)kv_ptr(h, li, 0), (_Float16*)kv_ptr(h, li, 1));
+      if (d / H == 32 && !scalar_pf) {
+        const int spad = (maxS + 31) / 32 * 32;
+        hipLaunchKernelGGL(prefill_vt_kernel, dim3(spad / 32, H, B), dim3(256), 0, s, (const _Float16*)h->pf_qkv, h->d_row_off,
+                           h->d_x_len, P, d, H, spad, (_Float16*)h->pf_vt);
+        hipLaunchKernelGGL(prefill_flash32_f16_kernel<4>, dim3(cdiv(maxS, 64), H, B), dim3(256), 0, s, (const _Float16*)h->pf_qkv,
+                           (const _Float16*)kv_ptr(h, li, 0), (const _Float16*)h->pf_vt, h->d_row_off, h->d_x_len, P, d, H,
+                           h->max_seq, spad, (_Float16*)h->pf_attn);
+      } else
       hipLaunchKernelGGL((prefill_attn_kernel<_Float16, 32>), dim3(cdiv(maxS, 64), H, B), dim3(64), 0, s,
                          (const _Float16*)h->pf_qkv, (const _Float16*)kv_ptr(h, li, 0), (const _Float16*)kv_ptr(h, li, 1),
                          h->d_row_off, h->d_x_len, P, d, H, h->max_seq, (_Float16*)h->pf_attn);
