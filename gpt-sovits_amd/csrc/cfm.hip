@@ -147,13 +147,14 @@ int launch_ln_mod(const void* x, const float* scale, const float* shift, int row
 // rotary embedding on the first 2*half channels of the q and k projections (x_transformers' apply_rotary_pos_emb on the
 // un-split [n, heads*dim_head] tensors, modules.py:420-427): adjacent pairs, angle = t * inv_freq[pair]
 template <typename T>
-__global__ void cfm_rope_kernel(T* __restrict__ qkv, int ld, int kcol0, int Tn, int half, const float* __restrict__ cs) {
+__global__ void cfm_rope_kernel(T* __restrict__ qkv, int ld, int kcol0, int rows, int Tn, int half, const float* __restrict__ cs) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Tn * half * 2) return;
-  const int which = i / (Tn * half);
-  const int r = i - which * Tn * half;
-  const int t = r / half, p = r - t * half;
-  T* v = qkv + (long long)t * ld + (which ? kcol0 : 0) + 2 * p;
+  if (i >= rows * half * 2) return;
+  const int which = i / (rows * half);
+  const int rr = i - which * rows * half;
+  const int row = rr / half, p = rr - row * half;
+  const int t = row % Tn;                                  // rows = batch * Tn: the position restarts per utterance
+  T* v = qkv + (long long)row * ld + (which ? kcol0 : 0) + 2 * p;
   const float c = cs[((long long)t * half + p) * 2], s = cs[((long long)t * half + p) * 2 + 1];
   const float a = to_f(v[0]), b = to_f(v[1]);
   v[0] = (T)(a * c - b * s);
@@ -193,16 +194,18 @@ __global__ void cfm_init_x_kernel(const float* __restrict__ noise, unsigned long
   x[i] = t < Tp ? 0.f : n * temperature;
 }
 
-// Euler update x += d * v (rows >= Tp; prompt rows stay 0, models.py:1083-1084) and refresh the x columns of the DiT input
+// Euler update x += d * v (rows >= Tp; prompt rows stay 0, models.py:1083-1084) and refresh the x columns of the DiT input;
+// rows = batch * Tn, the prompt region restarts per utterance
 template <typename T>
-__global__ void cfm_euler_kernel(float* __restrict__ x, const float* __restrict__ v, float d, int Tn, int Tp, int C, T* __restrict__ xin,
-                                 int ldin) {
+__global__ void cfm_euler_kernel(float* __restrict__ x, const float* __restrict__ v, float d, int rows, int Tn, int Tp, int C,
+                                 T* __restrict__ xin, int ldin) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)Tn * C) return;
-  int t = (int)(i / C), c = (int)(i - (long long)t * C);
+  if (i >= (long long)rows * C) return;
+  int row = (int)(i / C), c = (int)(i - (long long)row * C);
+  const int t = row % Tn;
   float u = t < Tp ? 0.f : x[i] + (v ? d * v[i] : 0.f);
   x[i] = u;
-  xin[(long long)t * ldin + c] = (T)u;
+  xin[(long long)row * ldin + c] = (T)u;
 }
 
 // prompt mel (channels-first [C][Tp]) -> the cond columns of the DiT input, zero after the prompt; also zeroes the pad columns
@@ -299,106 +302,125 @@ int cfm_modulations(gsv_cfm* c, hipStream_t s, int N, float** mods_out) {
   return GSV_OK;
 }
 
-// one utterance: mu [T][text_dim] fp32, prompt [mel][Tp] fp32, noise [mel][T] fp32 or null -> out [mel][T] fp32
+// B utterances of Tn frames: mu [B][Tn][text_dim] fp32, prompt [B][mel][Tp] fp32, noise [B][mel][Tn] fp32 or null -> out
+// [B][mel][Tn] fp32.  All row-wise work (Linear layers, AdaLN, rotary, Euler) runs over the B * Tn rows at once -- the
+// batched caller (TTS.py:1576-1579) hands over 4-8 chunks, which is what fills the chip and reads the 370 MB of weights
+// once per step instead of once per chunk; only the ops that look along time (depthwise / position convs, GRN, attention)
+// are issued per utterance.
 template <typename T>
-int cfm_infer_one(gsv_cfm* c, hipStream_t s, const float* mods, const float* mu, const float* prompt, int Tn, int Tp, int N,
-                  const float* noise, float temperature, unsigned long long seed, float* out) {
+int cfm_infer_batch(gsv_cfm* c, hipStream_t s, const float* mods, const float* mu, const float* prompt, int B, int Tn, int Tp, int N,
+                    const float* noise, float temperature, unsigned long long seed, float* out) {
   gsv_vits* h = &c->ctx;
   const auto& g = c->cfg;
   const int D = g.dim, td = g.text_dim, md = g.mel_dim, inner = g.heads * g.dim_head, FF = D * g.ff_mult, ldin = c->ldin;
   const int half = g.dim_head / 2;
   const size_t es = sizeof(T);
+  const int R = B * Tn;
   float *x, *v, *cs, *gx;
   void *xin, *ta, *tb, *tw, *hb, *c1, *nrm, *qkv, *ao, *ff;
-  GSV_RC(need(h, "cfm_x", (size_t)Tn * md * 4, (void**)&x));
-  GSV_RC(need(h, "cfm_v", (size_t)Tn * md * 4, (void**)&v));
+  GSV_RC(need(h, "cfm_x", (size_t)R * md * 4, (void**)&x));
+  GSV_RC(need(h, "cfm_v", (size_t)R * md * 4, (void**)&v));
   GSV_RC(need(h, "cfm_cs", (size_t)Tn * half * 2 * 4, (void**)&cs));
   GSV_RC(need(h, "cfm_gx", (size_t)2 * td * 4, (void**)&gx));
-  GSV_RC(need(h, "cfm_xin", (size_t)Tn * ldin * es, &xin));
-  GSV_RC(need(h, "cfm_ta", (size_t)Tn * td * es, &ta));
-  GSV_RC(need(h, "cfm_tb", (size_t)Tn * td * es, &tb));
-  GSV_RC(need(h, "cfm_tw", (size_t)Tn * 2 * td * es, &tw));
-  GSV_RC(need(h, "cfm_h", (size_t)Tn * D * es, &hb));
-  GSV_RC(need(h, "cfm_c1", (size_t)Tn * D * es, &c1));
-  GSV_RC(need(h, "cfm_nrm", (size_t)Tn * D * es, &nrm));
-  GSV_RC(need(h, "cfm_qkv", (size_t)Tn * 3 * inner * es, &qkv));
-  GSV_RC(need(h, "cfm_ao", (size_t)Tn * inner * es, &ao));
-  GSV_RC(need(h, "cfm_ff", (size_t)Tn * FF * es, &ff));
+  GSV_RC(need(h, "cfm_xin", (size_t)R * ldin * es, &xin));
+  GSV_RC(need(h, "cfm_ta", (size_t)R * td * es, &ta));
+  GSV_RC(need(h, "cfm_tb", (size_t)R * td * es, &tb));
+  GSV_RC(need(h, "cfm_tw", (size_t)R * 2 * td * es, &tw));
+  GSV_RC(need(h, "cfm_h", (size_t)R * D * es, &hb));
+  GSV_RC(need(h, "cfm_c1", (size_t)R * D * es, &c1));
+  GSV_RC(need(h, "cfm_nrm", (size_t)R * D * es, &nrm));
+  GSV_RC(need(h, "cfm_qkv", (size_t)R * 3 * inner * es, &qkv));
+  GSV_RC(need(h, "cfm_ao", (size_t)R * inner * es, &ao));
+  GSV_RC(need(h, "cfm_ff", (size_t)R * FF * es, &ff));
+  auto rows = [&](void* p, int b, int width) { return (void*)((char*)p + (size_t)b * Tn * width * es); };
 
   // ---- per-utterance constants: text embedding (dit.py:50-72), cond columns, rotary table
-  CFM_LAUNCH(cfm_text_pos_kernel<T>, (long long)Tn * td, mu, c->pos_table, Tn, td, (T*)ta);
-  for (auto& b : c->text) {
-    CFM_LAUNCH(cfm_dwconv7_kernel<T>, (long long)Tn * td, (const T*)ta, b.dw, b.db, Tn, td, (T*)tb);
-    GSV_RC(launch_layernorm(h->dtype, tb, 0, nullptr, 0, b.ng, b.nb, tb, 0, Tn, td, 1e-6f, s));
+  for (int b = 0; b < B; ++b)
+    CFM_LAUNCH(cfm_text_pos_kernel<T>, (long long)Tn * td, mu + (size_t)b * Tn * td, c->pos_table, Tn, td, (T*)rows(ta, b, td));
+  for (auto& blk : c->text) {
+    for (int b = 0; b < B; ++b)
+      CFM_LAUNCH(cfm_dwconv7_kernel<T>, (long long)Tn * td, (const T*)rows(ta, b, td), blk.dw, blk.db, Tn, td, (T*)rows(tb, b, td));
+    GSV_RC(launch_layernorm(h->dtype, tb, 0, nullptr, 0, blk.ng, blk.nb, tb, 0, R, td, 1e-6f, s));
     ConvOpt og; og.post_act = ACT_GELU;
-    GSV_RC(conv(h, s, b.pw1, tb, td, Tn, tw, Tn, og));
-    hipLaunchKernelGGL(cfm_grn_norm_kernel<T>, dim3(cdiv(2 * td, 64)), dim3(256), 0, s, (const T*)tw, Tn, 2 * td, gx);
-    hipLaunchKernelGGL(cfm_grn_apply_kernel<T>, dim3(std::min(1024, nblk((long long)Tn * 2 * td))), dim3(256), 0, s, (T*)tw, gx, b.gg,
-                       b.gb, Tn, 2 * td);
+    GSV_RC(conv(h, s, blk.pw1, tb, td, R, tw, R, og));
+    for (int b = 0; b < B; ++b) {                      // GRN statistics are per utterance (norm over its own frames)
+      T* twb = (T*)rows(tw, b, 2 * td);
+      hipLaunchKernelGGL(cfm_grn_norm_kernel<T>, dim3(cdiv(2 * td, 64)), dim3(256), 0, s, (const T*)twb, Tn, 2 * td, gx);
+      hipLaunchKernelGGL(cfm_grn_apply_kernel<T>, dim3(std::min(1024, nblk((long long)Tn * 2 * td))), dim3(256), 0, s, twb, gx, blk.gg,
+                         blk.gb, Tn, 2 * td);
+    }
     GSV_HIP(hipGetLastError());
     ConvOpt orr; orr.res = ta;
-    GSV_RC(conv(h, s, b.pw2, tw, 2 * td, Tn, ta, Tn, orr));
+    GSV_RC(conv(h, s, blk.pw2, tw, 2 * td, R, ta, R, orr));
   }
   {
     const int W = md + (ldin - (2 * md + td));
-    CFM_LAUNCH(cfm_cond_kernel<T>, (long long)Tn * W, prompt, Tn, Tp, md, (T*)xin, ldin, md, 2 * md + td);
-    hipLaunchKernelGGL((cfm_copy_cols_kernel<T>), dim3(nblk((long long)Tn * td)), dim3(256), 0, s, (const T*)ta, td, Tn, td, (T*)xin,
+    for (int b = 0; b < B; ++b)
+      CFM_LAUNCH(cfm_cond_kernel<T>, (long long)Tn * W, prompt ? prompt + (size_t)b * md * Tp : nullptr, Tn, Tp, md,
+                 (T*)rows(xin, b, ldin), ldin, md, 2 * md + td);
+    hipLaunchKernelGGL((cfm_copy_cols_kernel<T>), dim3(nblk((long long)R * td)), dim3(256), 0, s, (const T*)ta, td, R, td, (T*)xin,
                        ldin, 2 * md);
     GSV_HIP(hipGetLastError());
   }
   CFM_LAUNCH(cfm_rope_table_kernel, Tn * half, Tn, half, cs);
-  CFM_LAUNCH(cfm_init_x_kernel, (long long)Tn * md, noise, seed, temperature, Tn, Tp, md, x);
-  CFM_LAUNCH(cfm_euler_kernel<T>, (long long)Tn * md, x, (const float*)nullptr, 0.f, Tn, Tp, md, (T*)xin, ldin);
+  for (int b = 0; b < B; ++b)
+    CFM_LAUNCH(cfm_init_x_kernel, (long long)Tn * md, noise ? noise + (size_t)b * md * Tn : nullptr,
+               seed + 0x9E3779B97F4A7C15ull * (unsigned long long)b, temperature, Tn, Tp, md, x + (size_t)b * Tn * md);
+  CFM_LAUNCH(cfm_euler_kernel<T>, (long long)R * md, x, (const float*)nullptr, 0.f, R, Tn, Tp, md, (T*)xin, ldin);
 
   const float d = (float)(1.0 / N);
   const float att_scale = 1.f / sqrtf((float)g.dim_head);
+  const bool flash = h->dtype == GSV_F16 && g.dim_head == 64 && !c->materialized_attn;
+  void* vtb = nullptr;
+  if (flash) GSV_RC(need(h, "cfm_vt", (size_t)g.heads * 64 * ((Tn + 31) / 32 * 32) * 2, &vtb));
   for (int step = 0; step < N; ++step) {
     // ---- InputEmbedding (dit.py:75-84): proj(cat(x, cond, text)) then + ConvPositionEmbedding
     ConvOpt o;
-    GSV_RC(conv(h, s, c->in_proj, xin, ldin, Tn, hb, Tn, o));
-    {
+    GSV_RC(conv(h, s, c->in_proj, xin, ldin, R, hb, R, o));
+    for (int b = 0; b < B; ++b) {
       ConvArgs a;
       const int cg = D / 16;
-      a.x = hb; a.w = c->pos1.w; a.bias = c->pos1.b; a.y = c1;
+      a.x = rows(hb, b, D); a.w = c->pos1.w; a.bias = c->pos1.b; a.y = rows(c1, b, D);
       a.T_in = Tn; a.T_out = Tn; a.T_virt = Tn; a.Cin = cg; a.Cout = cg; a.taps = 31; a.pad = 15;
       a.ldx = D; a.ldw = 31 * cg; a.ldy = D; a.ldr = D; a.post_act = ACT_MISH;
       a.Z = 16; a.xz = cg; a.wz = (long long)cg * 31 * cg; a.yz = cg; a.bz = cg;
       GSV_RC(launch_conv_gemm(h->dtype, a, s));
-      a.x = c1; a.w = c->pos2.w; a.bias = c->pos2.b; a.y = hb; a.accumulate = 1;   // h += mish(conv2(.))
+      a.x = rows(c1, b, D); a.w = c->pos2.w; a.bias = c->pos2.b; a.y = rows(hb, b, D); a.accumulate = 1;   // h += mish(conv2(.))
       GSV_RC(launch_conv_gemm(h->dtype, a, s));
     }
     // ---- DiT blocks (modules.py:550-594)
     for (int l = 0; l < g.depth; ++l) {
-      const DitBlockW& b = c->blocks[l];
+      const DitBlockW& blk = c->blocks[l];
       const float* m = mods + ((size_t)l * N + step) * 6 * D;   // shift_a, scale_a, gate_a, shift_m, scale_m, gate_m
-      GSV_RC(launch_ln_mod<T>(hb, m + D, m, Tn, D, nrm, s));
-      GSV_RC(conv(h, s, b.qkv, nrm, D, Tn, qkv, Tn, o));
-      CFM_LAUNCH(cfm_rope_kernel<T>, Tn * half * 2, (T*)qkv, 3 * inner, inner, Tn, half, cs);
-      if (h->dtype == GSV_F16 && g.dim_head == 64 && !c->materialized_attn) {
-        void* vtb;
-        GSV_RC(need(h, "cfm_vt", (size_t)g.heads * 64 * ((Tn + 31) / 32 * 32) * 2, &vtb));
-        GSV_RC(launch_flash_attn64_f16(qkv, 3 * inner, (const _Float16*)qkv + inner, 3 * inner, (const _Float16*)qkv + 2 * inner, 3 * inner,
-                                       vtb, Tn, g.heads, att_scale, ao, inner, s));
-      } else {
-        GSV_RC(attention(h, s, qkv, 3 * inner, 0, qkv, 3 * inner, inner, 2 * inner, Tn, Tn, g.heads, g.dim_head, att_scale, nullptr,
-                         nullptr, ao, inner));
+      GSV_RC(launch_ln_mod<T>(hb, m + D, m, R, D, nrm, s));
+      GSV_RC(conv(h, s, blk.qkv, nrm, D, R, qkv, R, o));
+      CFM_LAUNCH(cfm_rope_kernel<T>, R * half * 2, (T*)qkv, 3 * inner, inner, R, Tn, half, cs);
+      for (int b = 0; b < B; ++b) {
+        const T* qb = (const T*)rows(qkv, b, 3 * inner);
+        if (flash) {
+          GSV_RC(launch_flash_attn64_f16(qb, 3 * inner, (const _Float16*)qb + inner, 3 * inner, (const _Float16*)qb + 2 * inner, 3 * inner,
+                                         vtb, Tn, g.heads, att_scale, rows(ao, b, inner), inner, s));
+        } else {
+          GSV_RC(attention(h, s, qb, 3 * inner, 0, qb, 3 * inner, inner, 2 * inner, Tn, Tn, g.heads, g.dim_head, att_scale, nullptr,
+                           nullptr, rows(ao, b, inner), inner));
+        }
       }
       ConvOpt og; og.gate = m + 2 * D; og.res = hb;
-      GSV_RC(conv(h, s, b.out, ao, inner, Tn, hb, Tn, og));
-      GSV_RC(launch_ln_mod<T>(hb, m + 4 * D, m + 3 * D, Tn, D, nrm, s));
+      GSV_RC(conv(h, s, blk.out, ao, inner, R, hb, R, og));
+      GSV_RC(launch_ln_mod<T>(hb, m + 4 * D, m + 3 * D, R, D, nrm, s));
       ConvOpt of; of.post_act = ACT_GELU_TANH;
-      GSV_RC(conv(h, s, b.ff1, nrm, D, Tn, ff, Tn, of));
+      GSV_RC(conv(h, s, blk.ff1, nrm, D, R, ff, R, of));
       ConvOpt o2; o2.gate = m + 5 * D; o2.res = hb;
-      GSV_RC(conv(h, s, b.ff2, ff, FF, Tn, hb, Tn, o2));
+      GSV_RC(conv(h, s, blk.ff2, ff, FF, R, hb, R, o2));
     }
     // ---- AdaLayerNormZero_Final (scale, shift) + proj_out, then the Euler step (models.py:1080-1084)
     const float* mf = mods + (size_t)g.depth * N * 6 * D + (size_t)step * 2 * D;
-    GSV_RC(launch_ln_mod<T>(hb, mf, mf + D, Tn, D, nrm, s));
+    GSV_RC(launch_ln_mod<T>(hb, mf, mf + D, R, D, nrm, s));
     ConvOpt ov; ov.out_f32 = 1;
-    GSV_RC(conv(h, s, c->proj_out, nrm, D, Tn, v, Tn, ov));
-    CFM_LAUNCH(cfm_euler_kernel<T>, (long long)Tn * md, x, (const float*)v, d, Tn, Tp, md, (T*)xin, ldin);
+    GSV_RC(conv(h, s, c->proj_out, nrm, D, R, v, R, ov));
+    CFM_LAUNCH(cfm_euler_kernel<T>, (long long)R * md, x, (const float*)v, d, R, Tn, Tp, md, (T*)xin, ldin);
   }
-  CFM_LAUNCH(cfm_out_kernel, (long long)Tn * md, x, Tn, md, out);
+  for (int b = 0; b < B; ++b) CFM_LAUNCH(cfm_out_kernel, (long long)Tn * md, x + (size_t)b * Tn * md, Tn, md, out + (size_t)b * md * Tn);
   return GSV_OK;
 }
 
@@ -506,15 +528,8 @@ int gsv_cfm_inference(gsv_cfm_t* c, const float* mu, const float* prompt, int B,
   float* mods = nullptr;
   if (c->ctx.dtype == GSV_F16) GSV_RC(cfm_modulations<_Float16>(c, s, n_steps, &mods));
   else GSV_RC(cfm_modulations<float>(c, s, n_steps, &mods));
-  for (int b = 0; b < B; ++b) {
-    const float* mu_b = mu + (size_t)b * T * g.text_dim;
-    const float* pr_b = prompt ? prompt + (size_t)b * g.mel_dim * Tp : nullptr;
-    const float* nz_b = noise ? noise + (size_t)b * g.mel_dim * T : nullptr;
-    float* out_b = out + (size_t)b * g.mel_dim * T;
-    const unsigned long long sd = (unsigned long long)seed + 0x9E3779B97F4A7C15ull * (unsigned long long)b;
-    if (c->ctx.dtype == GSV_F16) GSV_RC(cfm_infer_one<_Float16>(c, s, mods, mu_b, pr_b, T, Tp, n_steps, nz_b, temperature, sd, out_b));
-    else GSV_RC(cfm_infer_one<float>(c, s, mods, mu_b, pr_b, T, Tp, n_steps, nz_b, temperature, sd, out_b));
-  }
+  if (c->ctx.dtype == GSV_F16) GSV_RC(cfm_infer_batch<_Float16>(c, s, mods, mu, prompt, B, T, Tp, n_steps, noise, temperature, seed, out));
+  else GSV_RC(cfm_infer_batch<float>(c, s, mods, mu, prompt, B, T, Tp, n_steps, noise, temperature, seed, out));
   return GSV_OK;
 }
 

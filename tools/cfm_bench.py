@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--depth", type=int, default=22)
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="chunks per call (the batched caller passes 4-8)")
     a = ap.parse_args()
     from gsv.f5_tts.model.backbones.dit import DiT
     from gsv.module.models import CFM
@@ -39,7 +40,7 @@ def main():
               mel_dim=cfg["mel_dim"], text_dim=cfg["text_dim"], conv_layers=cfg["conv_layers"], device="cuda:0", dtype=dt)
     dit.load_state_dict(S.make_dit_state_dict(cfg, seed=1))
     cfm = CFM(100, dit)
-    mu = S.hash_symmetric("bench_mu", (1, a.frames, cfg["text_dim"]), 1.0, 1).cuda()
+    mu = S.hash_symmetric("bench_mu", (a.batch, a.frames, cfg["text_dim"]), 1.0, 1).cuda()
     prompt = S.hash_symmetric("bench_prompt", (1, 100, a.prompt), 1.0, 1).cuda()
     cfm.inference(mu, None, prompt, 2, seed=1)
     torch.cuda.synchronize()
@@ -49,9 +50,9 @@ def main():
         out = cfm.inference(mu, None, prompt, a.steps, seed=1)
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
-    fl = flops_per_step(cfg, a.frames)
+    fl = flops_per_step(cfg, a.frames) * a.batch
     print(json.dumps({"what": "cfm_inference", "dtype": "f32" if a.fp32 else "f16", "frames": a.frames, "prompt": a.prompt,
-                      "depth": a.depth, "steps": a.steps, "ms_total": best * 1e3, "ms_per_step": best * 1e3 / a.steps,
+                      "depth": a.depth, "batch": a.batch, "steps": a.steps, "ms_total": best * 1e3, "ms_per_step": best * 1e3 / a.steps,
                       "gflop_per_step": fl / 1e9, "tflops": fl * a.steps / best / 1e12,
                       "finite": bool(torch.isfinite(out).all())}))
 
