@@ -149,6 +149,11 @@ def main():
         pr = cProfile.Profile()
         pr.enable(); step(); torch.cuda.synchronize(); pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(35)
+    # server hygiene: objects built so far (checkpoints, engines, segments) leave the collector's working set, so a
+    # generation-2 collection cannot stall a timed step for ~100 ms
+    import gc
+    gc.collect()
+    gc.freeze()
     tok_count[0] = 0
     times = []
     if world > 1:
@@ -161,8 +166,8 @@ def main():
         torch.cuda.synchronize()
         times.append(time.perf_counter() - ts)
         if rank == 0:
-            log("step %d: %.1f ms, stages (text, to_batch, AR, SoVITS) = %s" % (len(times) - 1, 1e3 * times[-1],
-                ", ".join("%.1f" % (1e3 * v) for v in tts.last_timing)))
+            log("step %d: %.1f ms, stages (text, to_batch, AR, SoVITS, post) = %s" % (len(times) - 1, 1e3 * times[-1],
+                ", ".join("%.1f" % (1e3 * v) for v in list(tts.last_timing) + [getattr(tts, "last_postprocess_s", 0.0)])))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -269,8 +269,10 @@ int launch_gemm_sk(int dtype, const ConvArgs& a, hipStream_t s) {
   if (a.ldx % 8 != 0 || a.ldw % 8 != 0 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return 1;
   if (a.T_in < a.T_virt) return 1;
   // only where the 128 x 128 LDS-tiled kernel cannot fill the chip (< 1.5 workgroups per CU)
+  // and only for skinny M: at M = 5760 (AR prefill) the 128 x 128 kernel wins even at 0.7 workgroups per CU
+  // (17.7 vs 25.9 us at N = K = 512, 41 vs 53 us at K = 2048; tools/gemm_probe.py)
   const long long tiles128 = (long long)cdiv(a.T_virt, 128) * cdiv(a.Cout, 128);
-  if (tiles128 >= 384) return 1;
+  if (tiles128 >= 384 || a.T_virt > 2048) return 1;
   static const bool t64 = !(getenv("GSV_GEMM_T64") && getenv("GSV_GEMM_T64")[0] == '0');   // A/B switch
   if (t64 && a.Cin % 512 == 0) {
     static bool attr64 = false;

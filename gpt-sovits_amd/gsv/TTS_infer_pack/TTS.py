@@ -298,17 +298,29 @@ class TTS:
         dev = self.configs.device
         zero = torch.zeros(int(self.configs.sampling_rate * fragment_interval), dtype=self.precision, device=dev)
         frags = [f for batch in audio for f in batch]
-        # per-fragment peak without a host round trip per fragment: x / max(peak, 1) == x when peak <= 1
-        peaks = torch.stack([f.abs().max() if f.numel() else zero.new_zeros(()) for f in frags])
-        denom = torch.where(peaks > 1, peaks, torch.ones_like(peaks))
+        # per-fragment peak normalisation as ONE segmented reduction + ONE division over the concatenated fragments
+        # (x / max(peak, 1) == x when peak <= 1); the reference loops over fragments with a host sync each (TTS.py:1391-1396)
+        lens = [int(f.shape[0]) for f in frags]
+        flat_in = torch.cat(frags, dim=0) if frags else zero[:0]
+        lens_t = torch.tensor(lens, dtype=torch.int64, device=dev)
+        if flat_in.numel():
+            peaks = torch.segment_reduce(flat_in.abs().float(), "max", lengths=lens_t, unsafe=True).clamp_min(0)
+            peaks = torch.nan_to_num(peaks, nan=0.0, posinf=float("inf"), neginf=0.0)       # empty fragments
+            denom = torch.where(peaks > 1, peaks, torch.ones_like(peaks)).to(flat_in.dtype)
+            flat_in = flat_in / torch.repeat_interleave(denom, lens_t, output_size=flat_in.numel())
+        pieces = list(torch.split(flat_in, lens)) if lens else []
         k = 0
         for i, batch in enumerate(audio):
-            for j, frag in enumerate(batch):
-                audio[i][j] = torch.cat([frag / denom[k], zero], dim=0)
+            for j in range(len(batch)):
+                audio[i][j] = pieces[k]
                 k += 1
         flat = self.recovery_order(audio, batch_index_list) if split_bucket else [f for b in audio for f in b]
-        self.last_fragment_lengths = [int(f.shape[0]) for f in flat]      # used by gsv.sharding
-        wav = torch.cat(flat, dim=0)
+        self.last_fragment_lengths = [int(f.shape[0]) + int(zero.shape[0]) for f in flat]      # used by gsv.sharding
+        parts = []
+        for f in flat:
+            parts.append(f)
+            parts.append(zero)
+        wav = torch.cat(parts, dim=0) if parts else zero[:0]
         # (x * 32768).astype(int16): C-style truncation, +32768 wraps to -32768 exactly as numpy does on the
         # reference's host path; done on the device so only int16 crosses PCIe
         pcm = (wav * 32768).to(torch.int32).to(torch.int16)
@@ -544,7 +556,10 @@ class TTS:
                 if len(audio) == 0:
                     yield 16000, np.zeros(16000, dtype=np.int16)
                     return
-                yield self.audio_postprocess(audio, sr, batch_index_list, speed_factor, split_bucket, fragment_interval)
+                t6 = time.perf_counter()
+                result = self.audio_postprocess(audio, sr, batch_index_list, speed_factor, split_bucket, fragment_interval)
+                self.last_postprocess_s = time.perf_counter() - t6
+                yield result
         except Exception as e:
             traceback.print_exc()
             # the reference yields 1 s of silence, rebuilds both models, then re-raises (TTS.py:1352-1363)
