@@ -25,8 +25,27 @@ namespace gsv {
 
 __device__ __forceinline__ f4 mma16(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-// Vt[head][d][key] = V[key][head*64 + d], keys zero padded to ldv (a multiple of 32)
-__global__ __launch_bounds__(256) void vt_kernel(const _Float16* __restrict__ v, int ld, int T, int ldv, _Float16* __restrict__ vt) {
+// Vt[head][d][key] = V[key][head*64 + d], keys zero padded to ldv (a multiple of 32).  The extra grid plane z == heads
+// applies the DiT's rotary embedding in place to the first 2*rope_half channels of q and k (x_transformers'
+// apply_rotary_pos_emb on the un-split projections, modules.py:420-427): same launch, one kernel less per block.
+__global__ __launch_bounds__(256) void vt_kernel(const _Float16* __restrict__ v, int ld, int T, int ldv, _Float16* __restrict__ vt,
+                                                 int heads, _Float16* __restrict__ q, int ldq, _Float16* __restrict__ k, int ldk,
+                                                 const float* __restrict__ rope_cs, int rope_half) {
+  if ((int)blockIdx.z == heads) {
+    const int n = T * rope_half * 2;
+    const int stride = gridDim.x * gridDim.y * 256;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+      const int which = i / (T * rope_half);
+      const int rr = i - which * T * rope_half;
+      const int t = rr / rope_half, p = rr - t * rope_half;
+      _Float16* x = (which ? k + (long long)t * ldk : q + (long long)t * ldq) + 2 * p;
+      const float c = rope_cs[((long long)t * rope_half + p) * 2], sn = rope_cs[((long long)t * rope_half + p) * 2 + 1];
+      const float a = (float)x[0], b = (float)x[1];
+      x[0] = (_Float16)(a * c - b * sn);
+      x[1] = (_Float16)(b * c + a * sn);
+    }
+    return;
+  }
   __shared__ _Float16 tile[32][34];
   const int head = blockIdx.z, j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -189,12 +208,13 @@ static int launch_flash_qt(const void* q, int ldq, const void* k, int ldk, const
 
 // q / k: [T][ld] with head h at columns h*64..; v likewise; vt_buf: heads * 64 * ceil32(T) halfs of scratch
 int launch_flash_attn64_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldvv, void* vt_buf, int T, int heads,
-                            float scale, void* out, int ldo, hipStream_t s) {
+                            float scale, void* out, int ldo, hipStream_t s, const float* rope_cs, int rope_half) {
   GSV_REQUIRE(T >= 1 && heads >= 1, "flash_attn: empty problem");
   GSV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)out % 8) == 0,
               "flash_attn: operands must be 16-byte aligned with leading dims multiple of 8");
   const int ldv = (T + 31) / 32 * 32;
-  hipLaunchKernelGGL(vt_kernel, dim3(ldv / 32, 2, heads), dim3(256), 0, s, (const _Float16*)v, ldvv, T, ldv, (_Float16*)vt_buf);
+  hipLaunchKernelGGL(vt_kernel, dim3(ldv / 32, 2, heads + (rope_cs ? 1 : 0)), dim3(256), 0, s, (const _Float16*)v, ldvv, T, ldv,
+                     (_Float16*)vt_buf, heads, (_Float16*)const_cast<void*>(q), ldq, (_Float16*)const_cast<void*>(k), ldk, rope_cs, rope_half);
   static const int qt_env = getenv("GSV_FLASH_QT") ? atoi(getenv("GSV_FLASH_QT")) : 0;     // A/B switch
   // more query tiles per workgroup = fewer K / V fragment loads per query, but fewer workgroups: keep >= ~1 per CU
   int qt = qt_env ? qt_env : ((long long)cdiv(T, 64) * heads >= 200 ? 4 : ((long long)cdiv(T, 32) * heads >= 200 ? 2 : 1));

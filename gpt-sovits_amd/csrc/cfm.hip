@@ -394,12 +394,12 @@ int cfm_infer_batch(gsv_cfm* c, hipStream_t s, const float* mods, const float* m
       const float* m = mods + ((size_t)l * N + step) * 6 * D;   // shift_a, scale_a, gate_a, shift_m, scale_m, gate_m
       GSV_RC(launch_ln_mod<T>(hb, m + D, m, R, D, nrm, s));
       GSV_RC(conv(h, s, blk.qkv, nrm, D, R, qkv, R, o));
-      CFM_LAUNCH(cfm_rope_kernel<T>, R * half * 2, (T*)qkv, 3 * inner, inner, R, Tn, half, cs);
+      if (!flash) CFM_LAUNCH(cfm_rope_kernel<T>, R * half * 2, (T*)qkv, 3 * inner, inner, R, Tn, half, cs);   // else inside the V^T launch
       for (int b = 0; b < B; ++b) {
         const T* qb = (const T*)rows(qkv, b, 3 * inner);
         if (flash) {
           GSV_RC(launch_flash_attn64_f16(qb, 3 * inner, (const _Float16*)qb + inner, 3 * inner, (const _Float16*)qb + 2 * inner, 3 * inner,
-                                         vtb, Tn, g.heads, att_scale, rows(ao, b, inner), inner, s));
+                                         vtb, Tn, g.heads, att_scale, rows(ao, b, inner), inner, s, cs, half));
         } else {
           GSV_RC(attention(h, s, qb, 3 * inner, 0, qb, 3 * inner, inner, 2 * inner, Tn, Tn, g.heads, g.dim_head, att_scale, nullptr,
                            nullptr, rows(ao, b, inner), inner));

@@ -132,8 +132,9 @@ int launch_gemm_sk(int dtype, const ConvArgs& a, hipStream_t s);
 int launch_conv_lds(int dtype, const ConvArgs& a, hipStream_t s);
 
 // fused attention, fp16, head dim 64 (attn.hip); vt_buf: heads * 64 * ceil32(T) halfs of scratch
+// rope_cs != null: rotate the first 2*rope_half channels of q and k in place first (cos|sin table [T][rope_half][2])
 int launch_flash_attn64_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* vt_buf, int T, int heads,
-                            float scale, void* out, int ldo, hipStream_t s);
+                            float scale, void* out, int ldo, hipStream_t s, const float* rope_cs = nullptr, int rope_half = 0);
 
 // elementwise / small ops (ops.hip)
 int launch_layernorm(int dtype, const void* x, int x_f32, const void* res, int res_f32, const float* gamma,

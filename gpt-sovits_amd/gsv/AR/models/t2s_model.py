@@ -148,11 +148,12 @@ class Text2SemanticDecoder:
             torch.cuda.current_stream(dev).wait_stream(self.stream)
             idx = out_len.cpu().tolist()
             self.last_steps = steps.value
+            y_all = torch.cat([pr, out_tokens], dim=1).long()       # one concat for the batch; rows are sliced as views
             y_list = []
             for b in range(B):
                 n = idx[b] if idx[b] >= 0 else steps.value - 1
                 idx[b] = n
-                y_list.append(torch.cat([pr[b].long(), out_tokens[b, :n].long()]))
+                y_list.append(y_all[b, :P + n])
         return y_list, idx
 
     # ---- reference entry points -----------------------------------------------------
