@@ -206,6 +206,210 @@ static int launch_flash_qt(const void* q, int ldq, const void* k, int ldk, const
   return GSV_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// enc_p self-attention with window-4 relative positions (H10, reference module/attentions.py:227-258), fp16, head dim 96:
+// the same transposed-score construction; the relative-key bias b[i][r] = (q_i / sqrt(d)) . rel_k[r] is added to the
+// scores of the 9 keys |j - i| <= 4 (only the 2-3 chunks that straddle the diagonal take that path), their biased LOGITS
+// are parked in LDS (logits need no online rescaling), and the epilogue turns them into the band probabilities that
+// weight rel_v (attentions.py:253-256).  Replaces scores GEMM -> softmax_rows -> V transpose -> PV GEMM -> relv_add and
+// their 2 x T^2 x 6 bytes of HBM round trips (T = 6400 folded frames at the benchmark shape).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vt96_kernel(const _Float16* __restrict__ v, int ld, int T, int ldv, _Float16* __restrict__ vt) {
+  __shared__ _Float16 tile[32][34];
+  const int head = blockIdx.z, j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int j = j0 + i;
+    tile[i][tx] = j < T ? v[(long long)j * ld + head * 96 + c0 + tx] : (_Float16)0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int j = j0 + tx;
+    if (j < ldv) vt[((long long)head * 96 + c0 + i) * ldv + j] = tile[tx][i];
+  }
+}
+
+template <int QT>
+__global__ __launch_bounds__(256) void flash_rel96_f16_kernel(const _Float16* __restrict__ q, int ldq, const _Float16* __restrict__ k,
+                                                              int ldk, const _Float16* __restrict__ vt, int ldv, int T, float scale,
+                                                              const float* __restrict__ rel_k, const float* __restrict__ rel_v,
+                                                              _Float16* __restrict__ out, int ldo) {
+  constexpr int D = 96, KS = 3, DT = 6, W = 4, NB = 9, LDO = 100, BQ = 16 * QT;
+  extern __shared__ float smem[];
+  float* Os = smem;                                  // [4][BQ][LDO]
+  float* Ms = Os + 4 * BQ * LDO;                     // [4][BQ]
+  float* Ls = Ms + 4 * BQ;                           // [4][BQ]
+  float* Bias = Ls + 4 * BQ;                         // [BQ][NB]   relative-key bias per query
+  float* Sb = Bias + BQ * NB;                        // [BQ][NB]   biased logits of the band keys (-inf outside [0, T))
+  const int vid = xcd_virtual_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int head = vid / gridDim.x, q0 = (vid % gridDim.x) * BQ;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  h8 qf[QT][KS];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const _Float16* qp = q + (long long)min(q0 + 16 * t + r, T - 1) * ldq + head * D + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[t][ks] = *(const h8*)(qp + 32 * ks);
+  }
+  // relative-key bias: wave w computes the tiles t = w, w + 4, ...; each lane dots its 24 channels, the 4 lanes of a query sum
+  for (int i = threadIdx.x; i < BQ * NB; i += 256) Sb[i] = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    if ((t & 3) != wave) continue;
+#pragma unroll
+    for (int rr = 0; rr < NB; ++rr) {
+      float sdot = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sdot += (float)qf[t][ks][e] * rel_k[rr * D + ks * 32 + g * 8 + e];
+      sdot += __shfl_xor(sdot, 16, 64);
+      sdot += __shfl_xor(sdot, 32, 64);
+      if (g == 0) Bias[(16 * t + r) * NB + rr] = sdot * scale;
+    }
+  }
+  __syncthreads();
+  const _Float16* kh = k + head * D + g * 8;
+  const _Float16* vh = vt + (long long)head * D * ldv + (long long)r * ldv + 4 * g;
+  f4 o[QT][DT];
+  float m[QT], l[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    m[t] = -INFINITY; l[t] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[t][d] = (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int nchunks = (T + 31) >> 5, lastc = nchunks - 1;
+  struct KV { h8 ka[KS], kb[KS]; h4 va[DT], vb[DT]; };
+  auto fetch = [&](KV& f, int c) {
+    const int key0 = c << 5;
+    const _Float16* pa = kh + (long long)min(key0 + r, T - 1) * ldk;
+    const _Float16* pb = kh + (long long)min(key0 + 16 + r, T - 1) * ldk;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { f.ka[ks] = *(const h8*)(pa + 32 * ks); f.kb[ks] = *(const h8*)(pb + 32 * ks); }
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const _Float16* pv = vh + (long long)(d * 16) * ldv + key0;
+      f.va[d] = *(const h4*)pv;
+      f.vb[d] = *(const h4*)(pv + 16);
+    }
+  };
+  auto process = [&](const KV& f, int c, bool valid) {
+    const int key0 = c << 5;
+    h8 av[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) av[d] = (h8){f.va[d][0], f.va[d][1], f.va[d][2], f.va[d][3], f.vb[d][0], f.vb[d][1], f.vb[d][2], f.vb[d][3]};
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      f4 sa = (f4){0.f, 0.f, 0.f, 0.f}, sb = sa;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) { sa = mma16(f.ka[ks], qf[t][ks], sa); sb = mma16(f.kb[ks], qf[t][ks], sb); }
+      float p[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        p[i] = (valid && key0 + 4 * g + i < T) ? sa[i] * scale : -INFINITY;
+        p[4 + i] = (valid && key0 + 16 + 4 * g + i < T) ? sb[i] * scale : -INFINITY;
+      }
+      const int qt0 = q0 + 16 * t;
+      if (valid && key0 + 31 >= qt0 - W && key0 <= qt0 + 15 + W) {      // wave-uniform: this chunk touches the diagonal band
+        const int qi = qt0 + r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int j = key0 + (i < 4 ? 4 * g + i : 16 + 4 * g + i - 4);
+          const int rp = j - qi + W;
+          if (rp >= 0 && rp < NB && j < T && qi < T) {
+            p[i] += Bias[(16 * t + r) * NB + rp];
+            Sb[(16 * t + r) * NB + rp] = p[i];
+          }
+        }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mx = fmaxf(mx, p[i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m[t], mx);
+      const float alpha = __expf(m[t] - mnew);
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { p[i] = __expf(p[i] - mnew); ps += p[i]; }
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
+      l[t] = l[t] * alpha + ps;
+      m[t] = mnew;
+      const h8 pf = (h8){(_Float16)p[0], (_Float16)p[1], (_Float16)p[2], (_Float16)p[3], (_Float16)p[4], (_Float16)p[5], (_Float16)p[6], (_Float16)p[7]};
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        o[t][d] *= alpha;
+        o[t][d] = mma16(av[d], pf, o[t][d]);
+      }
+    }
+  };
+  KV fA, fB;
+  fetch(fA, min(wave, lastc));
+  for (int c = wave; c < nchunks; c += 8) {
+    fetch(fB, min(c + 4, lastc));
+    GSV_PIN();
+    process(fA, c, true);
+    GSV_PIN();
+    fetch(fA, min(c + 8, lastc));
+    GSV_PIN();
+    process(fB, c + 4, c + 4 < nchunks);
+    GSV_PIN();
+  }
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+#pragma unroll
+    for (int d = 0; d < DT; ++d) *(f4*)&Os[((size_t)wave * BQ + 16 * t + r) * LDO + d * 16 + 4 * g] = o[t][d];
+    if (g == 0) { Ms[wave * BQ + 16 * t + r] = m[t]; Ls[wave * BQ + 16 * t + r] = l[t]; }
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < BQ * (D / 4); it += 256) {
+    const int qq = it / (D / 4), d4 = (it % (D / 4)) * 4;
+    if (q0 + qq >= T) continue;
+    const float mt = fmaxf(fmaxf(Ms[qq], Ms[BQ + qq]), fmaxf(Ms[2 * BQ + qq], Ms[3 * BQ + qq]));
+    float den = 0.f;
+    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float e = __expf(Ms[w * BQ + qq] - mt);
+      den += e * Ls[w * BQ + qq];
+      acc += *(const f4*)&Os[((size_t)w * BQ + qq) * LDO + d4] * e;
+    }
+#pragma unroll
+    for (int rr = 0; rr < NB; ++rr) {
+      const float pw = __expf(Sb[qq * NB + rr] - mt);                   // band probability * den; exp(-inf) = 0 outside [0, T)
+      const f4 rv = *(const f4*)(rel_v + rr * D + d4);
+      acc += rv * pw;
+    }
+    const float inv = 1.f / den;
+    *(h4*)(out + (long long)(q0 + qq) * ldo + head * D + d4) =
+        (h4){(_Float16)(acc[0] * inv), (_Float16)(acc[1] * inv), (_Float16)(acc[2] * inv), (_Float16)(acc[3] * inv)};
+  }
+}
+
+// self-attention with relative positions (window 4), fp16, head dim 96; vt_buf: heads * 96 * ceil32(T) halfs of scratch
+int launch_flash_rel96_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldvv, void* vt_buf, int T, int heads,
+                           float scale, const float* rel_k, const float* rel_v, void* out, int ldo, hipStream_t s) {
+  GSV_REQUIRE(T >= 1 && heads >= 1 && rel_k && rel_v, "flash_rel96: bad argument");
+  GSV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)out % 8) == 0 &&
+              ((uintptr_t)rel_v % 16) == 0, "flash_rel96: operands must be 16-byte aligned with leading dims multiple of 8");
+  const int ldv = (T + 31) / 32 * 32;
+  hipLaunchKernelGGL(vt96_kernel, dim3(ldv / 32, 3, heads), dim3(256), 0, s, (const _Float16*)v, ldvv, T, ldv, (_Float16*)vt_buf);
+  constexpr int QT = 2;
+  const size_t lds = ((size_t)4 * 16 * QT * 100 + 8 * 16 * QT + 2 * 16 * QT * 9) * 4;
+  static bool attr = false;
+  if (!attr) {
+    GSV_HIP(hipFuncSetAttribute((const void*)flash_rel96_f16_kernel<QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  hipLaunchKernelGGL(flash_rel96_f16_kernel<QT>, dim3(cdiv(T, 16 * QT), heads), dim3(256), lds, s, (const _Float16*)q, ldq,
+                     (const _Float16*)k, ldk, (const _Float16*)vt_buf, ldv, T, scale, rel_k, rel_v, (_Float16*)out, ldo);
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
 // q / k: [T][ld] with head h at columns h*64..; v likewise; vt_buf: heads * 64 * ceil32(T) halfs of scratch
 int launch_flash_attn64_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldvv, void* vt_buf, int T, int heads,
                             float scale, void* out, int ldo, hipStream_t s, const float* rope_cs, int rope_half) {

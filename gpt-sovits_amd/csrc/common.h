@@ -136,6 +136,10 @@ int launch_conv_lds(int dtype, const ConvArgs& a, hipStream_t s);
 int launch_flash_attn64_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* vt_buf, int T, int heads,
                             float scale, void* out, int ldo, hipStream_t s, const float* rope_cs = nullptr, int rope_half = 0);
 
+// enc_p self-attention with window-4 relative positions, fp16, head dim 96 (attn.hip)
+int launch_flash_rel96_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* vt_buf, int T, int heads,
+                           float scale, const float* rel_k, const float* rel_v, void* out, int ldo, hipStream_t s);
+
 // elementwise / small ops (ops.hip)
 int launch_layernorm(int dtype, const void* x, int x_f32, const void* res, int res_f32, const float* gamma,
                      const float* beta, void* y, int y_f32, int rows, int C, float eps, hipStream_t s);

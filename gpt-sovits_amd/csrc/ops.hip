@@ -114,6 +114,13 @@ int gsv_op_flash_attn64(const void* qkv, int T, int heads, float scale, void* vt
                                       vt_scratch, T, heads, scale, out, inner, (hipStream_t)stream);
 }
 
+int gsv_op_flash_rel96(const void* qkv, int T, int heads, float scale, const float* rel_k, const float* rel_v, void* vt_scratch,
+                       void* out, gsv_stream_t stream) {
+  const int H = heads * 96;
+  return gsv::launch_flash_rel96_f16(qkv, 3 * H, (const _Float16*)qkv + H, 3 * H, (const _Float16*)qkv + 2 * H, 3 * H, vt_scratch, T, heads,
+                                     scale, rel_k, rel_v, out, H, (hipStream_t)stream);
+}
+
 int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream) {
   gsv::ConvArgs a;
   a.x = d->x; a.w = d->w; a.bias = d->bias; a.y = d->y; a.res = d->res; a.gate = d->gate;

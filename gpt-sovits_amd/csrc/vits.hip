@@ -521,6 +521,13 @@ int conv(gsv_vits* h, hipStream_t s, const Conv& c, const void* x, int ldx, int 
 int attention(gsv_vits* h, hipStream_t s, const void* q, int ldq, int qcol0, const void* kv, int ldkv, int kcol0, int vcol0,
               int Tq, int Tk, int nh, int kc, float scale, const float* rel_k, const float* rel_v, void* out, int ldo) {
   const size_t es = esz(h);
+  static const bool no_flash = getenv("GSV_MATERIALIZED_ENC_ATTN") != nullptr;    // A/B switch
+  if (!no_flash && h->dtype == GSV_F16 && kc == 96 && rel_k && rel_v && Tq == Tk && q == kv && ldq == ldkv) {
+    void* vtb;
+    GSV_RC(need(h, "att_vt96", (size_t)nh * 96 * ((Tk + 31) / 32 * 32) * 2, &vtb));
+    return launch_flash_rel96_f16((const _Float16*)q + qcol0, ldq, (const _Float16*)kv + kcol0, ldkv, (const _Float16*)kv + vcol0, ldkv,
+                                  vtb, Tq, nh, scale, rel_k, rel_v, out, ldo, s);
+  }
   const int G = h->dtype == GSV_F16 ? 8 : 4;
   const int ldp = (Tk + G - 1) / G * G;
   void *scores, *P, *Vt, *band;

@@ -235,6 +235,10 @@ typedef struct {
 /* fused softmax attention of the DiT blocks alone (fp16, head dim 64): qkv [dev] f16 [T][3*heads*64] (q | k | v column
  * blocks), vt_scratch [dev] heads*64*ceil32(T) halfs, out [dev] f16 [T][heads*64] */
 int gsv_op_flash_attn64(const void* qkv, int T, int heads, float scale, void* vt_scratch, void* out, gsv_stream_t stream);
+/* enc_p self-attention with window-4 relative positions alone (fp16, head dim 96, module/attentions.py:227-258):
+ * qkv [dev] f16 [T][3*heads*96], rel_k / rel_v [dev] fp32 [9][96], vt_scratch heads*96*ceil32(T) halfs, out f16 [T][heads*96] */
+int gsv_op_flash_rel96(const void* qkv, int T, int heads, float scale, const float* rel_k, const float* rel_v, void* vt_scratch,
+                       void* out, gsv_stream_t stream);
 /* channels-last conv1d: x [T_in][Cin], w [Cout][taps*Cin] (tap-major, cin fastest), y [T_out][Cout] */
 int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream);
 /* y = LN(x (+res)) over the last dim C; all buffers of `dtype`, gamma/beta fp32 */

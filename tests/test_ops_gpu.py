@@ -262,3 +262,44 @@ def test_skinny_gemm_matches_torch(T, K, N, post, use_res, use_gate):
     elif post == 6:
         ref = F.silu(ref)
     assert (y.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("T,heads", [(6400, 2), (37, 2), (5, 1), (1, 2), (200, 3)])
+def test_flash_rel96_matches_reference_formula(T, heads):
+    """fused enc_p attention (fp16, d = 96, window-4 relative keys / values) vs the reference's formula in torch fp32
+    (module/attentions.py:227-258: scores + q.rel_k on the band, softmax, p @ v + band(p) @ rel_v) on the same
+    fp16-rounded inputs: max-abs <= 5e-3."""
+    from gsv import _lib
+    from gsv import synthetic as S
+    _lib.init(0)
+    D, W = 96, 4
+    H = heads * D
+    qkv = (S.hash_symmetric(f"rel_qkv_{T}", (T, 3 * H), 1.2, 3)).to(DEV, torch.float16)
+    rel_k = S.hash_symmetric("rel_k", (2 * W + 1, D), 0.3, 3).to(DEV)
+    rel_v = S.hash_symmetric("rel_v", (2 * W + 1, D), 0.5, 3).to(DEV)
+    vt = torch.empty(heads * D * ((T + 31) // 32 * 32), dtype=torch.float16, device=DEV)
+    out = torch.empty(T, H, dtype=torch.float16, device=DEV)
+    scale = 1.0 / D ** 0.5
+    st = torch.cuda.current_stream()
+    _lib.check(_lib.lib().gsv_op_flash_rel96(qkv.data_ptr(), T, heads, scale, rel_k.data_ptr(), rel_v.data_ptr(), vt.data_ptr(),
+                                             out.data_ptr(), C.c_void_p(st.cuda_stream)))
+    torch.cuda.synchronize()
+    x = qkv.float()
+    rk, rv = rel_k, rel_v
+    ref = torch.empty(T, H, device=DEV)
+    idx = torch.arange(T, device=DEV)
+    rel = idx[None, :] - idx[:, None] + W                               # [T, T] band index, valid in [0, 2W]
+    inband = (rel >= 0) & (rel <= 2 * W)
+    for h in range(heads):
+        q = x[:, h * D:(h + 1) * D] * scale
+        k = x[:, H + h * D:H + (h + 1) * D]
+        v = x[:, 2 * H + h * D:2 * H + (h + 1) * D]
+        s = q @ k.t()
+        b = q @ rk.t()                                                  # [T, 9]
+        s = s + torch.where(inband, b.gather(1, rel.clamp(0, 2 * W)), torch.zeros((), device=DEV))
+        p = torch.softmax(s, -1)
+        o = p @ v
+        pb = torch.zeros(T, 2 * W + 1, device=DEV)
+        pb.scatter_add_(1, rel.clamp(0, 2 * W), torch.where(inband, p, torch.zeros((), device=DEV)))
+        ref[:, h * D:(h + 1) * D] = o + pb @ rv
+    assert (out.float() - ref).abs().max().item() <= 5e-3
