@@ -42,6 +42,10 @@ struct gsv_vits {
   Conv bridge, w1_pre, w1_proj, w1_cond;
   std::vector<Conv> w1_in, w1_res;
   std::vector<float*> w1_in_bias_eff;
+  // v2Pro: speaker-verification conditioning
+  Conv sv_emb, ge_to512;
+  float *prelu_w = nullptr, *ge_ref = nullptr, *sv_proj = nullptr, *ge512 = nullptr;
+  void* sv_t = nullptr;
   // ref_enc
   Conv r_sp0, r_sp3, r_t0, r_t1, r_qkv, r_fc, r_out;
   float* ge = nullptr;         // fp32 [gin]

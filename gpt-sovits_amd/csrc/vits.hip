@@ -307,6 +307,16 @@ __global__ void interp_nearest_kernel(const T* __restrict__ x, int Tin, int Tout
   for (int c = threadIdx.x; c < C; c += blockDim.x) y[(long long)t * C + c] = x[(long long)src * C + c];
 }
 
+// v2Pro: ge (+)= PReLU(ge_ref + sv_proj) * wgt   (module/models.py:971-975, then the mean over references)
+__global__ void sv_prelu_acc_kernel(const float* __restrict__ ge_ref, const float* __restrict__ sv_proj, const float* __restrict__ a,
+                                    float wgt, int accumulate, int n, float* __restrict__ ge) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = ge_ref[i] + sv_proj[i];
+  const float u = (v >= 0.f ? v : a[i] * v) * wgt;
+  ge[i] = accumulate ? ge[i] + u : u;
+}
+
 __global__ void vec_add_kernel(const float* a, const float* b, float* out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] + b[i];
@@ -699,7 +709,7 @@ int gsv_vits_finalize(gsv_vits_t* h) {
   const auto& c = h->cfg;
   const int H = c.hidden_channels, IC = c.inter_channels, GIN = c.gin_channels, SSL = c.ssl_dim;
   const int MH = 512;  // MRTE hidden (mrte_model.py:13)
-  GSV_REQUIRE(GIN == MH, "vits: gin_channels must equal the MRTE width 512 (mrte_model.py:36 adds ge to it)");
+  GSV_REQUIRE(GIN == MH || c.v2pro, "vits: gin_channels must equal the MRTE width 512 (mrte_model.py:36 adds ge to it)");
   // enc_p
   GSV_RC(make_conv(h, "enc_p.ssl_proj", H, SSL, 1, true, &h->ssl_proj_enc));
   GSV_RC(make_encoder(h, "enc_p.encoder_ssl", c.n_layers / 2, &h->enc_ssl));
@@ -794,13 +804,40 @@ int gsv_vits_finalize(gsv_vits_t* h) {
   GSV_RC(dalloc(h, (void**)&h->ge, (size_t)GIN * 4));
   GSV_RC(dalloc(h, &h->ge_t, (size_t)GIN * esz(h)));
   GSV_RC(dalloc(h, (void**)&h->mo_bias_eff, (size_t)MH * 4));
+  if (c.v2pro) {
+    GSV_RC(make_conv(h, "sv_emb", GIN, 20480, 1, true, &h->sv_emb));
+    GSV_RC(make_conv(h, "ge_to512", MH, GIN, 1, true, &h->ge_to512));
+    GSV_RC(make_vec(h, "prelu.weight", GIN, &h->prelu_w));
+    GSV_RC(dalloc(h, (void**)&h->ge_ref, (size_t)GIN * 4));
+    GSV_RC(dalloc(h, (void**)&h->sv_proj, (size_t)GIN * 4));
+    GSV_RC(dalloc(h, (void**)&h->ge512, (size_t)MH * 4));
+    GSV_RC(dalloc(h, &h->sv_t, (size_t)20480 * esz(h)));
+  }
   for (auto& e : h->ev) GSV_HIP(hipEventCreate(&e));
   h->staged.clear();
   h->finalized = true;
   return GSV_OK;
 }
 
+static int set_refer_impl(gsv_vits_t* h, const float* const* specs, const int* frames, int bins, const float* const* sv_embs, int n_refs,
+                          gsv_stream_t stream);
+
 int gsv_vits_set_refer(gsv_vits_t* h, const float* const* specs, const int* frames, int bins, int n_refs, gsv_stream_t stream) {
+  GSV_REQUIRE(h && h->finalized, "vits_set_refer: handle not finalized");
+  GSV_REQUIRE(!h->cfg.v2pro, "vits_set_refer: a v2Pro model needs gsv_vits_set_refer_sv (one sv embedding per reference)");
+  return set_refer_impl(h, specs, frames, bins, nullptr, n_refs, stream);
+}
+
+int gsv_vits_set_refer_sv(gsv_vits_t* h, const float* const* specs, const int* frames, int bins, const float* const* sv_embs,
+                          int n_refs, gsv_stream_t stream) {
+  GSV_REQUIRE(h && h->finalized, "vits_set_refer_sv: handle not finalized");
+  GSV_REQUIRE(h->cfg.v2pro && sv_embs, "vits_set_refer_sv: not a v2Pro model, or no sv embeddings");
+  for (int r = 0; r < n_refs; ++r) GSV_REQUIRE(sv_embs[r], "vits_set_refer_sv: missing sv embedding %d", r);
+  return set_refer_impl(h, specs, frames, bins, sv_embs, n_refs, stream);
+}
+
+static int set_refer_impl(gsv_vits_t* h, const float* const* specs, const int* frames, int bins, const float* const* sv_embs, int n_refs,
+                          gsv_stream_t stream) {
   GSV_REQUIRE(h && h->finalized, "vits_set_refer: handle not finalized");
   GSV_REQUIRE(specs && frames && n_refs >= 1, "vits_set_refer: no reference spectrogram");
   GSV_REQUIRE(bins >= h->cfg.ref_bins, "vits_set_refer: spectrogram has %d bins, need >= %d", bins, h->cfg.ref_bins);
@@ -837,9 +874,20 @@ int gsv_vits_set_refer(gsv_vits_t* h, const float* const* specs, const int* fram
     ConvOpt orr; orr.res = b; orr.ldr = RH;
     GSV_RC(conv(h, s, h->r_fc, a, RH, Tr, y2, Tr, orr));          // fc(attn) + residual -> y2 [Tr][RH]
     GSV_RC(conv(h, s, h->r_out, y2, RH, Tr, ao, Tr, o));            // [Tr][GIN]
-    GSV_DISPATCH(h,
-      hipLaunchKernelGGL(mean_time_kernel<_Float16>, dim3(cdiv(GIN, 64)), dim3(64), 0, s, (const _Float16*)ao, Tr, GIN, 1.f / n_refs, r > 0, h->ge),
-      hipLaunchKernelGGL(mean_time_kernel<float>, dim3(cdiv(GIN, 64)), dim3(64), 0, s, (const float*)ao, Tr, GIN, 1.f / n_refs, r > 0, h->ge));
+    if (!sv_embs) {
+      GSV_DISPATCH(h,
+        hipLaunchKernelGGL(mean_time_kernel<_Float16>, dim3(cdiv(GIN, 64)), dim3(64), 0, s, (const _Float16*)ao, Tr, GIN, 1.f / n_refs, r > 0, h->ge),
+        hipLaunchKernelGGL(mean_time_kernel<float>, dim3(cdiv(GIN, 64)), dim3(64), 0, s, (const float*)ao, Tr, GIN, 1.f / n_refs, r > 0, h->ge));
+    } else {
+      GSV_DISPATCH(h,
+        hipLaunchKernelGGL(mean_time_kernel<_Float16>, dim3(cdiv(GIN, 64)), dim3(64), 0, s, (const _Float16*)ao, Tr, GIN, 1.f, 0, h->ge_ref),
+        hipLaunchKernelGGL(mean_time_kernel<float>, dim3(cdiv(GIN, 64)), dim3(64), 0, s, (const float*)ao, Tr, GIN, 1.f, 0, h->ge_ref));
+      GSV_RC(launch_convert(sv_embs[r], h->sv_t, h->dtype, 20480, s));
+      ConvOpt osv; osv.out_f32 = 1;
+      GSV_RC(conv(h, s, h->sv_emb, h->sv_t, 20480, 1, h->sv_proj, 1, osv));
+      hipLaunchKernelGGL(sv_prelu_acc_kernel, dim3(cdiv(GIN, 256)), dim3(256), 0, s, (const float*)h->ge_ref, (const float*)h->sv_proj,
+                         (const float*)h->prelu_w, 1.f / n_refs, r > 0, GIN, h->ge);
+    }
   }
   GSV_RC(launch_convert(h->ge, h->ge_t, h->dtype, GIN, s));
   // fold conditioning into biases: conv_pre + cond(ge); MRTE conv_o bias + ge; WN in_layers + cond_layer(ge)
@@ -847,7 +895,12 @@ int gsv_vits_set_refer(gsv_vits_t* h, const float* const* specs, const int* fram
   GSV_RC(need(h, "cond_tmp", (size_t)2048 * 4 * 4, (void**)&tmp));
   {
     ConvOpt o; o.out_f32 = 1;
-    hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(GIN, 256)), dim3(256), 0, s, h->ge, h->mo.b, h->mo_bias_eff, GIN);
+    if (c.v2pro) {     // the MRTE adds ge_to512(ge) (models.py:997)
+      GSV_RC(conv(h, s, h->ge_to512, h->ge_t, GIN, 1, h->ge512, 1, o));
+      hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(512, 256)), dim3(256), 0, s, h->ge512, h->mo.b, h->mo_bias_eff, 512);
+    } else {
+      hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(GIN, 256)), dim3(256), 0, s, h->ge, h->mo.b, h->mo_bias_eff, GIN);
+    }
     if (c.flavor != 0) {
       GSV_RC(conv(h, s, h->w1_cond, h->ge_t, GIN, 1, tmp, 1, o));
       const int n = 2 * 512;

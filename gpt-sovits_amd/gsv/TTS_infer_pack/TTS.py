@@ -70,8 +70,8 @@ class TTS_Config:
         self.device = torch.device(configs.get("device", "cuda:0"))
         self.is_half = bool(configs.get("is_half", True))
         self.version = configs.get("version", "v2")
-        if self.version not in ("v1", "v2", "v3", "v4"):
-            raise NotImplementedError(f"version {self.version}: v1 / v2 / v3 / v4 are built; v2Pro(Plus) is out of scope")
+        if self.version not in ("v1", "v2", "v2Pro", "v2ProPlus", "v3", "v4"):
+            raise NotImplementedError(f"version {self.version} is not one of v1, v2, v2Pro, v2ProPlus, v3, v4")
         self.t2s_weights_path = configs.get("t2s_weights_path")
         self.vits_weights_path = configs.get("vits_weights_path")
         self.max_batch = int(configs.get("max_batch", 32))
@@ -188,10 +188,14 @@ class TTS:
     # ---- prompt cache (replaces set_ref_audio's HuBERT/STFT front-end, TTS.py:737-819) ---------
     def set_prompt_cache(self, prompt_semantic: torch.Tensor, refer_spec: Sequence[torch.Tensor],
                          phones: Optional[List[int]] = None, bert_features: Optional[torch.Tensor] = None,
-                         norm_text: str = "", ref_mel: Optional[torch.Tensor] = None):
+                         norm_text: str = "", ref_mel: Optional[torch.Tensor] = None,
+                         sv_emb: Optional[Sequence[torch.Tensor]] = None):
         """`ref_mel` (v3/v4 only): the log-mel of the reference audio as `mel_fn` / `mel_fn_v4` return it ([1, 100, Tm],
         TTS.py:67-88, 1453) -- computing it from the waveform is part of the audio front-end, outside this build."""
         self.prompt_cache["ref_mel"] = ref_mel
+        # v2Pro / v2ProPlus: one speaker-verification embedding [1, 20480] per reference spectrogram (reference sv.py:11-32,
+        # TTS.py:790-800 keeps it beside the spectrogram); computing it is the ERes2NetV2 front-end, outside this build
+        self.prompt_cache["sv_emb"] = list(sv_emb) if sv_emb is not None else None
         self.prompt_cache["prompt_semantic"] = prompt_semantic.to(self.configs.device)
         self.prompt_cache["refer_spec"] = [(s, None) for s in refer_spec]
         self.prompt_cache["phones"] = phones
@@ -489,6 +493,7 @@ class TTS:
             infer = (self.t2s_model.infer_panel_batch_infer if parallel_infer
                      else self.t2s_model.infer_panel_naive_batched)
             refer = [spec.to(device=self.configs.device) for spec, _ in self.prompt_cache["refer_spec"]]
+            sv_kw = {"sv_emb": self.prompt_cache["sv_emb"]} if getattr(self.vits_model, "is_v2pro", False) else {}
             up = math.prod(self.vits_model.upsample_rates)
             audio, t_34, t_45 = [], 0.0, 0.0
             sr = self.configs.sampling_rate if not self.configs.use_vocoder else self.vocoder_configs["sr"]
@@ -530,7 +535,7 @@ class TTS:
                         all_pred = torch.cat([pred[k] for k in keep]).view(1, 1, -1)
                         all_ph = torch.cat([item["phones"][k] for k in keep]).view(1, -1)
                         wav = self.vits_model.decode(all_pred, all_ph, refer, speed=speed_factor,
-                                                     seed=actual_seed + bi)[0, 0]
+                                                     seed=actual_seed + bi, **sv_kw)[0, 0]
                     else:
                         wav = torch.zeros(0, dtype=self.precision, device=self.configs.device)
                     o = 0
@@ -541,7 +546,7 @@ class TTS:
                 else:
                     for k, p in enumerate(pred):
                         frags.append(self.vits_model.decode(p.view(1, 1, -1), item["phones"][k].view(1, -1), refer,
-                                                            speed=speed_factor, seed=actual_seed + bi)[0, 0])
+                                                            speed=speed_factor, seed=actual_seed + bi, **sv_kw)[0, 0])
                 torch.cuda.synchronize(self.configs.device)
                 t5 = time.perf_counter()
                 t_45 += t5 - t4

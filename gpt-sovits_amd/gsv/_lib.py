@@ -27,7 +27,7 @@ class VitsConfig(C.Structure):
                                         "upsample_initial_channel", "n_ups")] + \
                [("up_rates", C.c_int * 8), ("up_kernels", C.c_int * 8), ("n_resblocks", C.c_int),
                 ("rb_kernels", C.c_int * 4), ("rb_dilations", (C.c_int * 3) * 4), ("ref_bins", C.c_int),
-                ("flavor", C.c_int)]
+                ("flavor", C.c_int), ("v2pro", C.c_int)]
 
 
 class VocoderConfig(C.Structure):
@@ -73,6 +73,8 @@ _SIGS = {
     "gsv_vits_finalize": (C.c_int, [C.c_void_p]),
     "gsv_vits_set_refer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                      C.c_void_p]),
+    "gsv_vits_set_refer_sv": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p),
+                                        C.c_int, C.c_void_p]),
     "gsv_vits_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
                                   C.c_double, C.c_uint64, C.c_void_p, C.c_void_p]),
     "gsv_vits_encp_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),

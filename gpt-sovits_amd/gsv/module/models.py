@@ -16,8 +16,8 @@ from .. import _lib
 
 
 class SynthesizerTrn:
-    _VERSIONS = ("v1", "v2")
-    _FLAVOR = {"v1": 0, "v2": 0, "v3": 1, "v4": 2}
+    _VERSIONS = ("v1", "v2", "v2Pro", "v2ProPlus")
+    _FLAVOR = {"v1": 0, "v2": 0, "v2Pro": 0, "v2ProPlus": 0, "v3": 1, "v4": 2}
 
     def __init__(self, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads, n_layers,
                  kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
@@ -25,8 +25,7 @@ class SynthesizerTrn:
                  semantic_frame_rate=None, freeze_quantizer=None, version="v2", device="cuda:0", dtype=torch.float16,
                  n_symbols: Optional[int] = None, **kwargs):
         if version not in self._VERSIONS:
-            raise NotImplementedError(f"{type(self).__name__} does not implement SoVITS {version} (v2Pro is out of scope, "
-                                      "SURVEY section 8f)")
+            raise NotImplementedError(f"{type(self).__name__} does not implement SoVITS {version}")
         if str(resblock) != "1":
             raise NotImplementedError("only ResBlock1 generators (reference configs/s2.json)")
         if semantic_frame_rate != "25hz":
@@ -37,7 +36,7 @@ class SynthesizerTrn:
         self.hidden_channels = hidden_channels
         self.upsample_rates = list(upsample_rates)
         self.semantic_frame_rate = semantic_frame_rate
-        self.is_v2pro = False
+        self.is_v2pro = version in ("v2Pro", "v2ProPlus")       # reference module/models.py:590, 895
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("gsv SynthesizerTrn runs on an MI355X (cuda/HIP device) only; there is no CPU path")
@@ -61,6 +60,7 @@ class SynthesizerTrn:
                 cfg.rb_dilations[j][c] = d
         cfg.ref_bins = spec_channels if version == "v1" else 704
         cfg.flavor = self._FLAVOR[version]
+        cfg.v2pro = int(self.is_v2pro)
         with torch.cuda.device(self.device):
             _lib.init(idx)
             h = C.c_void_p()
@@ -98,17 +98,32 @@ class SynthesizerTrn:
         return self
 
     # ---- reference audio -------------------------------------------------------------
-    def _set_refer(self, refer: Union[torch.Tensor, Sequence[torch.Tensor]]):
+    def _set_refer(self, refer: Union[torch.Tensor, Sequence[torch.Tensor]], sv_emb=None):
         refs = list(refer) if isinstance(refer, (list, tuple)) else [refer]
-        key = tuple((r.data_ptr(), tuple(r.shape), r._version) for r in refs)
+        svs = None
+        if self.is_v2pro:
+            if sv_emb is None:
+                raise ValueError("a v2Pro / v2ProPlus model needs sv_emb (one [1, 20480] embedding per reference, sv.py:11-32)")
+            svs = list(sv_emb) if isinstance(sv_emb, (list, tuple)) else [sv_emb]
+            if len(svs) != len(refs) or any(v.numel() != 20480 for v in svs):
+                raise ValueError("sv_emb: expected one [1, 20480] tensor per reference spectrogram")
+        elif sv_emb is not None:
+            raise ValueError("sv_emb is only used by v2Pro / v2ProPlus models")
+        key = tuple((r.data_ptr(), tuple(r.shape), r._version) for r in refs + (svs or []))
         if key == self._ref_key:
             return
         keep = [r.to(self.device, torch.float32).contiguous() for r in refs]
         ptrs = (C.c_void_p * len(keep))(*[r.data_ptr() for r in keep])
         frames = (C.c_int * len(keep))(*[int(r.shape[2]) for r in keep])
         bins = int(keep[0].shape[1])
-        _lib.check(_lib.lib().gsv_vits_set_refer(self._h, ptrs, frames, bins, len(keep),
-                                                 C.c_void_p(self.stream.cuda_stream)), "gsv_vits_set_refer")
+        if svs is None:
+            _lib.check(_lib.lib().gsv_vits_set_refer(self._h, ptrs, frames, bins, len(keep),
+                                                     C.c_void_p(self.stream.cuda_stream)), "gsv_vits_set_refer")
+        else:
+            keep_sv = [v.reshape(-1).to(self.device, torch.float32).contiguous() for v in svs]
+            sv_ptrs = (C.c_void_p * len(keep_sv))(*[v.data_ptr() for v in keep_sv])
+            _lib.check(_lib.lib().gsv_vits_set_refer_sv(self._h, ptrs, frames, bins, sv_ptrs, len(keep),
+                                                        C.c_void_p(self.stream.cuda_stream)), "gsv_vits_set_refer_sv")
         self.stream.synchronize()
         self._ref_key = key
 
@@ -120,8 +135,6 @@ class SynthesizerTrn:
         `noise` (optional, [inter, 2T]) injects the randn_like draw of models.py:1000 for parity tests."""
         if not self._loaded:
             raise RuntimeError("load_state_dict() first")
-        if sv_emb is not None:
-            raise NotImplementedError("v2Pro speaker-verification conditioning is out of scope (SURVEY section 8f N4)")
         if codes.numel() == 0 or text.numel() == 0:
             raise ValueError("decode needs at least one semantic token and one phoneme")
         T = int(codes.shape[-1])
@@ -129,7 +142,7 @@ class SynthesizerTrn:
         up = math.prod(self.upsample_rates)
         with torch.cuda.device(self.device):
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
-            self._set_refer(refer)
+            self._set_refer(refer, sv_emb)
             cd = codes.reshape(-1).to(self.device, torch.int32).contiguous()
             tx = text.reshape(-1).to(self.device, torch.int32).contiguous()
             frames = 2 * T if speed == 1 else int(2 * T / speed) + 1      # models.py:226-228

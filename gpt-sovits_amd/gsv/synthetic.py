@@ -342,6 +342,13 @@ def make_vits_state_dict(config=None, seed: int = 0) -> "OrderedDict[str, torch.
     sd["quantizer.vq.layers.0._codebook.inited"] = torch.ones(1)
     sd["quantizer.vq.layers.0._codebook.cluster_size"] = torch.ones(NBINS)
     sd["quantizer.vq.layers.0._codebook.embed_avg"] = sd["quantizer.vq.layers.0._codebook.embed"].clone()
+    if m.get("version") in ("v2Pro", "v2ProPlus"):
+        # speaker-verification conditioning (reference module/models.py:895-899): sv_emb 20480 -> gin, PReLU(gin), ge_to512
+        sd["sv_emb.weight"] = _w("sv_emb.weight", (GIN, 20480), 20480, 1.0, seed)
+        sd["sv_emb.bias"] = _b("sv_emb.bias", GIN, 0.05, seed)
+        sd["ge_to512.weight"] = _w("ge_to512.weight", (512, GIN), GIN, 1.0, seed)
+        sd["ge_to512.bias"] = _b("ge_to512.bias", 512, 0.05, seed)
+        sd["prelu.weight"] = 0.25 + hash_symmetric("prelu.weight", (GIN,), 0.2, seed)
     return sd
 
 

@@ -117,6 +117,8 @@ typedef struct {
   int ref_bins;             /* 704 (v2): leading spectrogram bins fed to ref_enc */
   int flavor;               /* 0 = v1/v2 SynthesizerTrn (flow + generator); 1 = v3, 2 = v4 SynthesizerTrnV3 (bridge + wns1,
                                nearest x1.875 / x2; no flow / generator weights: the mel comes from gsv_cfm_inference) */
+  int v2pro;                /* 1 = v2Pro / v2ProPlus conditioning (module/models.py:895-899): sv_emb 20480 -> gin, PReLU(gin),
+                               ge_to512 for the MRTE; gin_channels may then differ from 512 */
 } gsv_vits_config;
 
 int gsv_vits_create(const gsv_vits_config* cfg, int dtype, gsv_vits_t** out);
@@ -146,6 +148,11 @@ int gsv_vits_debug_tensor(gsv_vits_t* h, const char* name, float* out, int64_t c
 int gsv_vits_encp_frames(gsv_vits_t* h, int T, double speed);
 int gsv_vits_decode_encp(gsv_vits_t* h, const int32_t* codes, int T, const int32_t* phones, int L, double speed, float* fea,
                          gsv_stream_t stream);
+/* v2Pro / v2ProPlus (N4, module/models.py:971-975): as gsv_vits_set_refer, plus one speaker-verification embedding per
+ * reference (sv_embs [host] array of n_refs [dev] fp32 pointers to 20480 values): ge_r = PReLU(ref_enc(spec_r) + sv_emb(sv_r)),
+ * ge = mean_r ge_r; the MRTE receives ge_to512(ge). */
+int gsv_vits_set_refer_sv(gsv_vits_t* h, const float* const* specs, const int* frames, int bins, const float* const* sv_embs,
+                          int n_refs, gsv_stream_t stream);
 /* per-kernel timing hooks for bench.py: device ms of the last decode's generator section */
 int gsv_vits_last_timing(gsv_vits_t* h, float* total_ms, float* generator_ms);
 

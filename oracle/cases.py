@@ -58,11 +58,18 @@ VITS_CASES = {
     "vits_v2": dict(cfg="v2", seed=0, T=10, L=8, Tr=[40], noise_scale=0.5),
     # speed != 1: linear interpolation of the encoder output (reference models.py:226-228)
     "vits_small_speed": dict(cfg="small", seed=6, T=11, L=7, Tr=[21], noise_scale=0.5, speed=1.3),
+    # v2Pro conditioning (N4): gin 1024, ge += sv_emb(sv); PReLU; MRTE gets ge_to512(ge) (models.py:895-899, 971-975, 997)
+    "vits_small_v2pro": dict(cfg="small", seed=8, T=9, L=6, Tr=[22, 15], noise_scale=0.5, version="v2Pro"),
 }
 
 
 def vits_case_inputs(case):
     cfg = S.small_vits_config() if case["cfg"] == "small" else S.VITS_V2_CONFIG
+    if case.get("version") in ("v2Pro", "v2ProPlus"):
+        import copy
+        cfg = copy.deepcopy(cfg)
+        cfg["model"]["version"] = case["version"]
+        cfg["model"]["gin_channels"] = 1024              # reference configs/s2v2Pro.json
     sd = S.make_vits_state_dict(cfg, seed=case["seed"])
     codes = torch.from_numpy(S.hash_ints("codes", case["T"], 1024, case["seed"])).view(1, 1, -1)
     text = torch.from_numpy(S.hash_ints("text", case["L"], cfg["n_symbols"], case["seed"])).view(1, -1)
@@ -73,6 +80,13 @@ def vits_case_inputs(case):
     noise = S.hash_normal("vits_noise", (cfg["model"]["inter_channels"], frames), case["seed"])
     ssl = S.hash_symmetric("ssl", (1, 768, 2 * case["T"]), 1.0, case["seed"])
     return cfg, sd, codes, text, refers, noise, ssl
+
+
+def vits_case_sv_emb(case):
+    """speaker-verification embeddings (one [1, 20480] per reference) of a v2Pro case, else None"""
+    if case.get("version") not in ("v2Pro", "v2ProPlus"):
+        return None
+    return [S.hash_symmetric(f"sv_emb{i}", (1, 20480), 1.0, case["seed"]) for i in range(len(case["Tr"]))]
 
 
 

@@ -20,14 +20,16 @@ from oracle import ref_import  # noqa: E402
 from oracle.vits_oracle import VitsOracle  # noqa: E402
 from oracle import aa_oracle  # noqa: E402
 
-from oracle.cases import VITS_CASES, vits_case_inputs  # noqa: E402
+from oracle.cases import VITS_CASES, vits_case_inputs, vits_case_sv_emb  # noqa: E402
 
 
 def build_reference_vits(cfg, sd):
     cls = ref_import.synthesizer_cls()
     d = cfg["data"]
+    mk = dict(cfg["model"])
+    version = mk.pop("version", "v2")
     model = cls(d["filter_length"] // 2 + 1, cfg["train"]["segment_size"] // d["hop_length"],
-                n_speakers=d["n_speakers"], version="v2", **cfg["model"])
+                n_speakers=d["n_speakers"], version=version, **mk)
     res = model.load_state_dict(sd, strict=False)
     bad = [k for k in res.missing_keys if not (k.startswith("enc_q") or "_codebook" in k)]
     assert not bad and not res.unexpected_keys, (bad, res.unexpected_keys)
@@ -42,14 +44,15 @@ def gen_vits():
         torch.randn_like = lambda t, **kw: noise.unsqueeze(0).to(t.dtype)
         try:
             with torch.no_grad():
-                ref_wav = model.decode(codes, text, refers, noise_scale=case["noise_scale"], speed=case.get("speed", 1))
+                ref_wav = model.decode(codes, text, refers, noise_scale=case["noise_scale"], speed=case.get("speed", 1),
+                                       sv_emb=vits_case_sv_emb(case))
                 ref_codes = model.extract_latent(ssl)
         finally:
             torch.randn_like = orig
         orc = VitsOracle(sd, cfg)
         col = {}
         wav = orc.decode(codes, text, refers, noise_scale=case["noise_scale"], noise=noise, collect=col,
-                         speed=case.get("speed", 1))
+                         speed=case.get("speed", 1), sv_emb=vits_case_sv_emb(case))
         ocodes = orc.extract_latent(ssl)
         err = (wav - ref_wav).abs().max().item()
         print(f"[gen_golden] {name}: wav {tuple(ref_wav.shape)} |ref| max {ref_wav.abs().max():.3f} "

@@ -256,15 +256,26 @@ class VitsOracle:
     # ---- H7 -------------------------------------------------------------------
     @torch.no_grad()
     def decode(self, codes: torch.Tensor, text: torch.Tensor, refer, noise_scale: float = 0.5,
-               noise: Optional[torch.Tensor] = None, collect: Optional[dict] = None, speed: float = 1) -> torch.Tensor:
+               noise: Optional[torch.Tensor] = None, collect: Optional[dict] = None, speed: float = 1,
+               sv_emb=None) -> torch.Tensor:
         """codes [1,1,T] int64, text [1,L] int64, refer: tensor or list of [1,bins,Tr];
         noise: the randn draw of models.py:1000, shape [inter, 2T] (None -> torch RNG).
         Returns [1, 1, 2T*prod(upsample_rates)]."""
         refs = refer if isinstance(refer, (list, tuple)) else [refer]
-        ge = torch.stack([self.ref_enc(r) for r in refs], 0).mean(0)      # [512, 1]
+        ges = []
+        for i, r in enumerate(refs):
+            g = self.ref_enc(r)                                             # [gin, 1]
+            if sv_emb is not None:                                          # v2Pro (models.py:971-975): + sv_emb(sv), PReLU
+                sv = sv_emb[i] if isinstance(sv_emb, (list, tuple)) else sv_emb
+                g = g + self.lin(sv.float().view(1, -1), "sv_emb").t()
+                a = self.sd["prelu.weight"].view(-1, 1)
+                g = torch.where(g >= 0, g, a * g)
+            ges.append(g)
+        ge = torch.stack(ges, 0).mean(0)
+        ge_enc = ge if sv_emb is None else self.lin(ge.t(), "ge_to512").t()   # MRTE gets ge_to512(ge) (models.py:997)
         q = self.sd["quantizer.vq.layers.0._codebook.embed"][codes[0, 0].long()].t()   # [768, T]
         q = q.repeat_interleave(2, dim=1)                                   # nearest x2
-        m_p, logs_p = self.enc_p(q, text[0].long(), ge, speed)
+        m_p, logs_p = self.enc_p(q, text[0].long(), ge_enc, speed)
         if noise is None:
             noise = torch.randn_like(m_p)
         z_p = m_p + noise * torch.exp(logs_p) * noise_scale

@@ -14,9 +14,11 @@ DEV = "cuda:0"
 def _engine(cfg, sd, dtype):
     from gsv.module.models import SynthesizerTrn
     d = cfg["data"]
+    mk = dict(cfg["model"])
+    version = mk.pop("version", "v2")
     m = SynthesizerTrn(d["filter_length"] // 2 + 1, cfg["train"]["segment_size"] // d["hop_length"],
-                       n_speakers=d["n_speakers"], version="v2", device=DEV, dtype=dtype, n_symbols=cfg["n_symbols"],
-                       **cfg["model"])
+                       n_speakers=d["n_speakers"], version=version, device=DEV, dtype=dtype, n_symbols=cfg["n_symbols"],
+                       **mk)
     m.load_state_dict(sd)
     return m
 
@@ -144,3 +146,30 @@ def test_vocoders_match_reference(name):
     err = out16 - g
     assert np.abs(err).max() <= 3e-2
     assert np.sqrt((err ** 2).mean()) <= 0.05 * np.sqrt((g ** 2).mean())
+
+
+def test_v2pro_conditioning_matches_reference():
+    """v2Pro (N4): ge = mean_r PReLU(ref_enc(spec_r) + sv_emb(sv_r)) with gin 1024, the MRTE fed ge_to512(ge)
+    (reference module/models.py:895-899, 971-975, 997), two references: fp32 engine vs the reference's waveform (golden)
+    <= 1e-4, ge <= 1e-4; fp16 engine <= 2e-2; error behaviour of the sv_emb argument."""
+    case = cases.VITS_CASES["vits_small_v2pro"]
+    cfg, sd, codes, text, refers, noise, ssl = cases.vits_case_inputs(case)
+    sv = cases.vits_case_sv_emb(case)
+    g = load_golden("vits_small_v2pro")
+    eng = _engine(cfg, sd, torch.float32)
+    wav = eng.decode(codes.to(DEV), text.to(DEV), [r.to(DEV) for r in refers], noise_scale=case["noise_scale"], noise=noise,
+                     sv_emb=[v.to(DEV) for v in sv])
+    ge = eng.debug_tensor("ge", 1024).cpu().numpy()
+    assert np.abs(ge - g["ge"].reshape(-1)).max() < 1e-4
+    assert np.abs(wav.float().cpu().numpy() - g["wav"]).max() <= 1e-4
+    with pytest.raises(ValueError):
+        eng.decode(codes.to(DEV), text.to(DEV), [r.to(DEV) for r in refers], noise=noise)                 # sv_emb missing
+    with pytest.raises(ValueError):
+        eng.decode(codes.to(DEV), text.to(DEV), [r.to(DEV) for r in refers], noise=noise, sv_emb=[sv[0].to(DEV)])
+    w16 = _engine(cfg, sd, torch.float16).decode(codes.to(DEV), text.to(DEV), [r.to(DEV) for r in refers],
+                                                 noise_scale=case["noise_scale"], noise=noise, sv_emb=sv).float().cpu().numpy()
+    assert np.abs(w16 - g["wav"]).max() <= 2e-2
+    v2 = _engine(*cases.vits_case_inputs(cases.VITS_CASES["vits_small"])[:2], torch.float32)
+    with pytest.raises(ValueError):
+        c2 = cases.vits_case_inputs(cases.VITS_CASES["vits_small"])
+        v2.decode(c2[2].to(DEV), c2[3].to(DEV), [r.to(DEV) for r in c2[4]], sv_emb=sv[0])                  # not a v2Pro model
