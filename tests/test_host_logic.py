@@ -134,3 +134,24 @@ def test_run_error_protocol_without_engines():
     assert sr == 16000 and audio.shape == (16000,) and audio.dtype == np.int16 and not audio.any()
     with pytest.raises(RuntimeError):
         next(gen)
+
+
+def test_text_segmentation_methods_match_reference_outputs():
+    """N1: cut0..cut5 / split / split_big_text against outputs of the reference module
+    (TTS_infer_pack/text_segmentation_method.py, run in the build container; tests/golden/text_segmentation.json)."""
+    import json
+    import os
+    from gsv.TTS_infer_pack import text_segmentation_method as seg
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "text_segmentation.json"), encoding="utf-8"))
+    texts = g["texts"]
+    assert sorted(seg.get_method_names()) == sorted(g["methods"])
+    for name, outs in g["methods"].items():
+        fn = seg.get_method(name)
+        for t, want in zip(texts, outs):
+            assert fn(t) == want, (name, t)
+    for t, want in zip([t for t in texts if t.strip("\n")], g["split"]):
+        assert seg.split(t) == want
+    for t, want in zip(texts, g["split_big_text"]):
+        assert seg.split_big_text(t, 40) == want
+    with pytest.raises(ValueError):
+        seg.get_method("cut9")
