@@ -12,6 +12,8 @@
 //   * rows are padded by 16 B so ds_read_b128 of 16 consecutive rows hits 64 distinct banks;
 //   * wave tile 64x128 (TM=2, TN=4 MFMA 32x32 tiles): 6 LDS fragment reads per 8 MFMAs.
 // Epilogue (bias, residual, scale, accumulate, tanh/relu, polyphase scatter) is the one of conv_gemm.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gsv {
@@ -535,6 +537,16 @@ template <typename T> static int try_launch(const ConvArgs& a, hipStream_t s) {
   const int lo = a.dil < 0 ? (a.taps - 1) * a.dil : 0;
   const int rows = 256 + span;                  // every configuration owns 256 time steps
   if (a.Cout > 64) {
+    // mid-size problems (enc_p / flow convs over a few thousand frames: 50-150 tiles of 256 steps) cannot fill the
+    // chip with 256-step tiles and each tile is a long dependent chain; halve the tile to double the workgroups
+    // (SoVITS 23.9 -> 23.2 ms per bench step; 64-step tiles for the smallest grids measured no further gain)
+    static const bool no_half = getenv("GSV_CONV_NO_HALF_TILE") != nullptr;      // A/B switch
+    const long long wgs256 = (long long)cdiv(a.T_virt, 256) * cdiv(a.Cout, 128);
+    if (!no_half && wgs256 < 192) {
+      const int rows128 = 128 + span;
+      if (a.Cin >= CCBIG && fits<T, 128, CCBIG>(rows128)) return launch_inst<T, 2, 2, 2, 2, CCBIG, false>(a, rows128, lo, s);
+      if (a.Cin >= CCBIG / 2 && fits<T, 128, CCBIG / 2>(rows128)) return launch_inst<T, 2, 2, 2, 2, CCBIG / 2, false>(a, rows128, lo, s);
+    }
     if (a.Cin >= CCBIG && fits<T, 128, CCBIG>(rows)) return launch_inst<T, 2, 4, 2, 2, CCBIG, false>(a, rows, lo, s);
     if (a.Cin >= CCBIG / 2 && fits<T, 128, CCBIG / 2>(rows)) return launch_inst<T, 2, 4, 2, 2, CCBIG / 2, false>(a, rows, lo, s);
     return 1;
