@@ -1475,9 +1475,9 @@ extern "C" {
 int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_lens, int B, const float* bert,
                     const int32_t* prompts, int P, gsv_stream_t stream) {
   GSV_REQUIRE(h && h->finalized, "t2s_prefill: handle not finalized");
-  GSV_REQUIRE(phones && phone_lens && prompts, "t2s_prefill: null argument");
+  GSV_REQUIRE(phones && phone_lens && (prompts || P == 0), "t2s_prefill: null argument");
   GSV_REQUIRE(B >= 1 && B <= h->max_batch, "t2s_prefill: batch %d exceeds max_batch %d", B, h->max_batch);
-  GSV_REQUIRE(P >= 1, "t2s_prefill: prompt-free decode is not supported (P=%d)", P);
+  GSV_REQUIRE(P >= 0, "t2s_prefill: negative prompt length %d", P);   // P == 0: prompt-free decode (t2s_model.py:849-856)
   hipStream_t s = (hipStream_t)stream;
   const auto& c = h->cfg;
   const int d = c.dim, H = c.n_head;
@@ -1505,7 +1505,8 @@ int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_le
   GSV_HIP(hipMemcpyAsync(h->d_active, ones.data(), B * 4, hipMemcpyHostToDevice, s));
   GSV_HIP(hipMemcpyAsync(h->d_step, zeros.data(), B * 4, hipMemcpyHostToDevice, s));
   GSV_HIP(hipMemcpyAsync(h->d_n_active, &B, 4, hipMemcpyHostToDevice, s));
-  GSV_HIP(hipMemcpy2DAsync(h->d_ytok, (size_t)h->ycap * 4, prompts, (size_t)P * 4, (size_t)P * 4, B, hipMemcpyDeviceToDevice, s));
+  if (P > 0)
+    GSV_HIP(hipMemcpy2DAsync(h->d_ytok, (size_t)h->ycap * 4, prompts, (size_t)P * 4, (size_t)P * 4, B, hipMemcpyDeviceToDevice, s));
   GSV_HIP(hipStreamSynchronize(s));  // host vectors above go out of scope
 
   const float* bertp = nullptr;

@@ -99,9 +99,9 @@ class Text2SemanticDecoder:
         if not self._loaded:
             raise RuntimeError("load_state_dict() first")
         B = len(x)
-        if prompts is None:
-            raise NotImplementedError("prompt-free synthesis is outside the hot-path scope (SURVEY.md section 8)")
         dev = self.device
+        if prompts is None:                  # prompt-free (reference t2s_model.py:849-856): empty audio prefix
+            prompts = torch.zeros(B, 0, dtype=torch.int64)
         l = _lib.lib()
         with torch.cuda.device(dev):
             lens = [int(t.shape[-1]) for t in x]
@@ -139,7 +139,8 @@ class Text2SemanticDecoder:
                 sp.early_stop_num = -1   # the arena bound (max_steps) ends generation first
             s = C.c_void_p(self.stream.cuda_stream)
             _lib.check(l.gsv_t2s_prefill(self._h, phones.data_ptr(), C.cast(lens_h, C.c_void_p), B,
-                                         bert_dev.data_ptr() if bert_dev is not None else None, pr.data_ptr(), P, s),
+                                         bert_dev.data_ptr() if bert_dev is not None else None,
+                                         pr.data_ptr() if P > 0 else None, P, s),
                        "gsv_t2s_prefill")
             steps = C.c_int(0)
             _lib.check(l.gsv_t2s_decode(self._h, C.byref(sp), noise_dev.data_ptr() if noise_dev is not None else None,
@@ -191,7 +192,7 @@ class Text2SemanticDecoder:
         y, i = self._run([x[0]], prompts, [bert_feature[0] if bert_feature is not None else None], top_k, top_p, early_stop_num, temperature,
                          repetition_penalty, eos_mask_steps=11, noise=kwargs.get("noise"), seed=kwargs.get("seed", 0),
                          max_steps=kwargs.get("max_steps", 1500))
-        return y[0].unsqueeze(0), i[0]
+        return y[0].unsqueeze(0), (0 if prompts is None else i[0])      # prompt-free reports idx 0 (t2s_model.py:916-917)
 
     @torch.no_grad()
     def infer_panel_naive_batched(self, x, x_lens, prompts, bert_feature, top_k: int = -100, top_p: int = 100,

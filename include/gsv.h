@@ -79,7 +79,8 @@ int gsv_t2s_finalize(gsv_t2s_t* h);
 
 /* Prefill (H2+H3): phones [dev] int32 packed, phone_lens [host] int32[B], bert [dev] fp32
  * [sum(X_b)][bert_dim] row-major (token-major; NULL = all zeros, the non-zh path), prompts [dev]
- * int32 [B][P].  Leaves the KV cache and per-row state ready for gsv_t2s_decode. */
+ * int32 [B][P]; P == 0 (prompts may be NULL) is the reference's prompt-free mode (t2s_model.py:849-856: the audio sequence
+ * starts empty at position 0).  Leaves the KV cache and per-row state ready for gsv_t2s_decode. */
 int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_lens, int B,
                     const float* bert, const int32_t* prompts, int P, gsv_stream_t stream);
 

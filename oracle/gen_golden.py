@@ -70,6 +70,42 @@ def run_reference_t2s(cfg, sd, xs, berts, prompts, noise, case, naive=False):
     return [t.clone() for t in ys], [int(i) for i in idxs], logits_trace
 
 
+def gen_t2s_ref_free():
+    """prompt-free naive decode (reference t2s_model.py:849-856, 916-917): reference vs oracle, greedy and sampled"""
+    for name in ("t2s_small_greedy", "t2s_small_topk"):
+        case = T2S_CASES[name]
+        cfg, sd, xs, berts, prompts, noise = t2s_case_inputs(case)
+        ref_import.setup()
+        import AR.models.utils as ru
+        model = ref_import.t2s_decoder_cls()(cfg)
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        step = {"i": 0}
+        orig_mn = ru.multinomial_sample_one_no_sync
+
+        def patched_mn(probs):
+            q = noise[step["i"]][:, : probs.shape[1]].expand_as(probs)
+            step["i"] += 1
+            return torch.argmax(probs / q, dim=-1, keepdim=True).to(dtype=torch.int)
+
+        if noise is not None:
+            ru.multinomial_sample_one_no_sync = patched_mn
+        kw = dict(top_k=case["top_k"], top_p=case["top_p"], temperature=case["temperature"],
+                  early_stop_num=case["early_stop"], repetition_penalty=case["rep"])
+        try:
+            with torch.no_grad():
+                y, idx = model.infer_panel_naive(xs[0].unsqueeze(0), torch.LongTensor([xs[0].shape[0]]), None,
+                                                 berts[0].unsqueeze(0), **kw)
+        finally:
+            ru.multinomial_sample_one_no_sync = orig_mn
+        nz = None if noise is None else noise[:, :1]
+        oy, oidx = T2SOracle(sd, cfg).infer_panel_naive(xs[0].unsqueeze(0), None, None, berts[0].unsqueeze(0), noise=nz, **kw)
+        ok = int(idx) == oidx == 0 and torch.equal(y[0].long(), oy[0].long())
+        print(f"[gen_golden] {name}_ref_free: tokens {y.shape[1]} idx={int(idx)} oracle_match={ok}")
+        assert ok
+        np.savez_compressed(os.path.join(GOLD, name + "_ref_free.npz"), y=y[0].numpy().astype(np.int64))
+
+
 def gen_t2s():
     for name, case in T2S_CASES.items():
         cfg, sd, xs, berts, prompts, noise = t2s_case_inputs(case)
@@ -125,6 +161,8 @@ if __name__ == "__main__":
     if "voc" in what:
         from oracle.gen_golden_vits import gen_voc
         gen_voc()
+    if "reffree" in what:
+        gen_t2s_ref_free()
     if "encp" in what:
         from oracle.gen_golden_vits import gen_encp
         gen_encp()

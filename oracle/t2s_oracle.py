@@ -268,9 +268,11 @@ class T2SOracle:
                           noise: Optional[torch.Tensor] = None, **kwargs):
         """x [1, X], prompts [1, P], bert [1, 1024, X]; EOS masked while idx < 11
         (t2s_model.py:888-889); returns (y[:, :-1], idx) (t2s_model.py:916-918)."""
-        assert prompts is not None, "prompt-free decode is out of scope (SURVEY section 8)"
+        ref_free = prompts is None            # t2s_model.py:849-856: y starts empty, positions start at 0, idx reported as 0
+        if ref_free:
+            prompts = torch.zeros(1, 0, dtype=torch.long)
         ys, idxs = self.infer_panel_batch_infer([x[0]], None, prompts, [bert_feature[0]], top_k=top_k, top_p=top_p,
                                                 early_stop_num=early_stop_num, temperature=temperature,
                                                 repetition_penalty=repetition_penalty, noise=noise,
                                                 eos_mask_steps=11, **kwargs)
-        return ys[0].unsqueeze(0), idxs[0]
+        return ys[0].unsqueeze(0), (0 if ref_free else idxs[0])

@@ -7,6 +7,7 @@ from conftest import load_golden
 from oracle import cases
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 
 
 def _split(flat, lens):
@@ -151,3 +152,21 @@ def test_full_size_fixed_length_batch_properties():
     y5, _ = eng.infer_panel_batch_infer(xs[5:6], None, prompts[5:6], berts[5:6], **kw)
     agree = sum(int(a == b) for a, b in zip(y5[0].tolist(), ys[5].tolist()))
     assert agree >= 100 + 20
+
+
+@pytest.mark.parametrize("name", ["t2s_small_greedy", "t2s_small_topk"])
+def test_prompt_free_naive_matches_reference(name):
+    """prompt-free decode (reference t2s_model.py:849-856, 916-917: empty audio prefix, positions from 0, idx reported
+    as 0): fp32 engine token ids bit-exact vs the reference golden, greedy and top-k with injected noise."""
+    from gsv.AR.models.t2s_model import Text2SemanticDecoder
+    case = cases.T2S_CASES[name]
+    cfg, sd, xs, berts, prompts, noise = cases.t2s_case_inputs(case)
+    g = load_golden(name + "_ref_free")["y"]
+    eng = Text2SemanticDecoder(cfg, device=DEV, dtype=torch.float32, max_batch=4, max_seq=256)
+    eng.load_state_dict(sd)
+    nz = None if noise is None else noise[:, :1]
+    y, idx = eng.infer_panel_naive(xs[0].unsqueeze(0).to(DEV), None, None, berts[0].unsqueeze(0).to(DEV), top_k=case["top_k"],
+                                   top_p=case["top_p"], temperature=case["temperature"], early_stop_num=case["early_stop"],
+                                   repetition_penalty=case["rep"], noise=nz)
+    assert idx == 0
+    assert y[0].cpu().tolist() == g.tolist()
