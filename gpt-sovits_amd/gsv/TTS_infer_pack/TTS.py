@@ -196,7 +196,7 @@ class TTS:
         # v2Pro / v2ProPlus: one speaker-verification embedding [1, 20480] per reference spectrogram (reference sv.py:11-32,
         # TTS.py:790-800 keeps it beside the spectrogram); computing it is the ERes2NetV2 front-end, outside this build
         self.prompt_cache["sv_emb"] = list(sv_emb) if sv_emb is not None else None
-        self.prompt_cache["prompt_semantic"] = prompt_semantic.to(self.configs.device)
+        self.prompt_cache["prompt_semantic"] = prompt_semantic.to(self.configs.device) if prompt_semantic is not None else None
         self.prompt_cache["refer_spec"] = [(s, None) for s in refer_spec]
         self.prompt_cache["phones"] = phones
         self.prompt_cache["bert_features"] = bert_features
@@ -467,7 +467,8 @@ class TTS:
         try:
             if self.t2s_model is None or self.vits_model is None:
                 raise RuntimeError("init_t2s_weights / init_vits_weights first")
-            if self.prompt_cache["prompt_semantic"] is None or not self.prompt_cache["refer_spec"]:
+            if not self.prompt_cache["refer_spec"] or (self.prompt_cache["prompt_semantic"] is None
+                                                       and self.prompt_cache["phones"] is not None):
                 raise NO_PROMPT_ERROR("set_prompt_cache() first (reference: ref_audio_path is required)")
             t0 = time.perf_counter()
             segments = inputs.get("segments")
@@ -503,7 +504,12 @@ class TTS:
             for bi, item in enumerate(data):
                 t3 = time.perf_counter()
                 n = len(item["all_phones"])
-                prompt = self.prompt_cache["prompt_semantic"].view(1, -1).expand(n, -1)
+                # no prompt text (reference TTS.py:1124-1131, 1223-1226): nothing is prepended and the AR decoder runs
+                # prompt-free through the naive loop; v3/v4 require a prompt (TTS.py:1062-1063)
+                no_prompt = prompt_data is None
+                if no_prompt and self.configs.use_vocoder:
+                    raise NO_PROMPT_ERROR("v3/v4 need the prompt text (phones) of the reference audio")
+                prompt = None if no_prompt else self.prompt_cache["prompt_semantic"].view(1, -1).expand(n, -1)
                 max_sec = self.configs.max_sec if self.configs.max_sec is not None else 54
                 pred_list, idx_list = infer(item["all_phones"], item["all_phones_len"], prompt,
                                             item["all_bert_features"], top_k=top_k, top_p=top_p, temperature=temperature,
@@ -512,7 +518,11 @@ class TTS:
                 torch.cuda.synchronize(self.configs.device)
                 t4 = time.perf_counter()
                 t_34 += t4 - t3
-                pred = [p[-i:] if i > 0 else p[:0] for p, i in zip(pred_list, idx_list)]
+                if no_prompt:     # idx is reported as 0 and y holds only generated tokens (t2s_model.py:916-917)
+                    pred = list(pred_list)
+                    idx_list = [int(p.shape[0]) for p in pred]
+                else:
+                    pred = [p[-i:] if i > 0 else p[:0] for p, i in zip(pred_list, idx_list)]
                 self.last_generated_tokens += int(sum(idx_list))
                 frags: List[torch.Tensor] = []
                 if self.configs.use_vocoder:

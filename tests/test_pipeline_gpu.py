@@ -122,3 +122,47 @@ def test_get_tts_wav_cli_path_matches_oracle_tokens_and_scaling():
     up = math.prod(vcfg["model"]["upsample_rates"])
     assert audio.shape[0] == n_tok * 2 * up + 2 * int(32000 * 0.3)
     assert sr == 32000 and audio.dtype == np.int16 and np.abs(audio).max() <= 32767
+
+
+def test_tts_run_prompt_free_matches_oracle_chain():
+    """no prompt text (reference TTS.py:1124-1131): nothing is prepended, the AR decoder starts from an empty audio prefix
+    (naive loop per sentence, EOS masked for 11 steps) and the whole generated sequence goes to the SoVITS decoder."""
+    tts, tcfg, tsd, vcfg, vsd = _build()
+    utt = S.make_utterances(3, prompt_phones=6, target_phones=9, prompt_tokens=8, seed=23, ragged=True)
+    refer = S.make_refer_spec(frames=30, seed=5)
+    segs = [{"phones": it["phones"], "bert_features": torch.zeros(1024, len(it["phones"])), "norm_text": "x" * (5 + i)}
+            for i, it in enumerate(utt["items"])]
+    tts.set_prompt_cache(None, [refer.to(DEV)], phones=None)
+    real_decode = tts.vits_model.decode
+    IC = vcfg["model"]["inter_channels"]
+    noises = []
+
+    def decode_with_noise(codes, text, refer_, **kw):
+        nz = S.hash_normal(f"pf_noise{len(noises)}", (IC, 2 * codes.shape[-1]), 0)
+        noises.append(nz)
+        kw.pop("seed", None)
+        return real_decode(codes, text, refer_, noise=nz, **kw)
+
+    tts.vits_model.decode = decode_with_noise
+    out = list(tts.run({"segments": segs, "batch_size": 3, "top_k": 1, "seed": 3, "split_bucket": False, "fragment_interval": 0.01}))
+    sr, audio = out[0]
+    t2s, vits = T2SOracle(tsd, tcfg), VitsOracle(vsd, vcfg)
+    up = math.prod(vcfg["model"]["upsample_rates"])
+    pred = []
+    for it in segs:
+        ph = torch.tensor(it["phones"])
+        y, idx = t2s.infer_panel_naive(ph.unsqueeze(0), None, None, torch.zeros(1, 1024, ph.shape[0]), top_k=1, top_p=1.0,
+                                       temperature=1.0, early_stop_num=20, repetition_penalty=1.35)
+        assert idx == 0
+        pred.append(y[0])
+    wav = vits.decode(torch.cat(pred).view(1, 1, -1), torch.cat([torch.tensor(it["phones"]) for it in segs]).view(1, -1), [refer],
+                      noise=noises[0])[0, 0]
+    zero = torch.zeros(int(32000 * 0.01))
+    parts, o = [], 0
+    for p in pred:
+        f = wav[o:o + p.shape[0] * 2 * up]
+        o += p.shape[0] * 2 * up
+        parts += [f / max(1.0, float(f.abs().max())), zero]
+    ref = (torch.cat(parts) * 32768).to(torch.int32).to(torch.int16).numpy()
+    assert audio.shape == ref.shape
+    assert np.abs(audio.astype(np.int32) - ref.astype(np.int32)).max() <= 4
