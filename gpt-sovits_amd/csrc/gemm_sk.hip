@@ -268,11 +268,14 @@ int launch_gemm_sk(int dtype, const ConvArgs& a, hipStream_t s) {
   if (a.Cin % 64 != 0 || a.Cin < 256 || a.Cout < 64) return 1;
   if (a.ldx % 8 != 0 || a.ldw % 8 != 0 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return 1;
   if (a.T_in < a.T_virt) return 1;
-  // only where the 128 x 128 LDS-tiled kernel cannot fill the chip (< 1.5 workgroups per CU)
+  // only where the 128 x 128 LDS-tiled kernel cannot fill the chip
   // and only for skinny M: at M = 5760 (AR prefill) the 128 x 128 kernel wins even at 0.7 workgroups per CU
   // (17.7 vs 25.9 us at N = K = 512, 41 vs 53 us at K = 2048; tools/gemm_probe.py)
   const long long tiles128 = (long long)cdiv(a.T_virt, 128) * cdiv(a.Cout, 128);
-  if (tiles128 >= 384 || a.T_virt > 2048) return 1;
+  // measured in the DiT step (tools/cfm_bench.py, GSV_SK_MAX_TILES): 384 -> 3.16, 160 -> 3.02, 100 -> 3.31 ms per step, i.e. the
+  // QKV projection (192 tiles) is better off on the 128 x 128 kernel, FF1 (128 tiles) and the N = 1024 layers are not
+  static const int max_tiles = getenv("GSV_SK_MAX_TILES") ? atoi(getenv("GSV_SK_MAX_TILES")) : 160;
+  if (tiles128 >= max_tiles || a.T_virt > 2048) return 1;
   static const bool t64 = !(getenv("GSV_GEMM_T64") && getenv("GSV_GEMM_T64")[0] == '0');   // A/B switch
   if (t64 && a.Cin % 512 == 0) {
     static bool attr64 = false;
