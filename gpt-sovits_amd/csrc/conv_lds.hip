@@ -320,7 +320,13 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
-  const int t0 = blockIdx.x * TT, cout0 = blockIdx.y * CT;
+  // XCD-aware tile order (unbatched launches): each XCD's L2 keeps a contiguous band of output-channel tiles' weights
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (gridDim.z == 1 && a.xcd_order) {
+    const int vid = xcd_virtual_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    bx = vid % gridDim.x; by = vid / gridDim.x;
+  }
+  const int t0 = bx * TT, cout0 = by * CT;
   const int z = blockIdx.z;                            // batch (attention heads): operand / output offsets
   const T* __restrict__ x = (const T*)a.x + (long long)z * a.xz;
   const T* __restrict__ w = (const T*)a.w + (long long)z * a.wz;
@@ -476,16 +482,19 @@ template <typename T> static int try_launch_gemm(const ConvArgs& a, hipStream_t 
   if (a.ldx % G != 0 || a.ldw % G != 0 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return 1;
   const size_t lds = (size_t)2 * (128 + 128) * (BK + G) * sizeof(T);     // 73.7 KB; epilogue tile 33.8 KB fits inside
   dim3 grid(cdiv(a.T_virt, 128), cdiv(a.Cout, 128), a.Z);
+  static const bool xcd = !(getenv("GSV_GEMM_XCD") && getenv("GSV_GEMM_XCD")[0] == '0');     // A/B switch
+  ConvArgs b = a;
+  b.xcd_order = xcd ? 1 : 0;
   if (a.res) {
     auto kern = gemm_lds_kernel<T, true>;
     static bool set = false;
     if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
   } else {
     auto kern = gemm_lds_kernel<T, false>;
     static bool set = false;
     if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
   }
   GSV_HIP(hipGetLastError());
   return GSV_OK;
