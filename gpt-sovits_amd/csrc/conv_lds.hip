@@ -14,6 +14,8 @@
 // Epilogue (bias, residual, scale, accumulate, tanh/relu, polyphase scatter) is the one of conv_gemm.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace gsv {
@@ -533,6 +535,185 @@ template <typename T, int CT, int CC> static bool fits(int rows, int wslabs = 2)
   return ((size_t)rows + (size_t)wslabs * CT) * (CC + DT<T>::G) * sizeof(T) <= 160 * 1024;
 }
 
+// ---------------------------------------------------------------------------------------
+// Narrow layers (C_in = C_out <= 32: the last two generator stages, 4.1 M and 2 M time steps of 16 / 32 channels).
+// They are pure HBM streaming (131 MB per tensor, ~nothing to multiply), and one 256-step tile per workgroup made
+// every tile a serial chain  load window -> LDS -> MFMA -> LDS transpose -> store  plus a reload of all 11 tap slabs:
+// 184-244 us per conv against 52-79 us of HBM time.  Here a workgroup is PERSISTENT over tiles: the weights of all
+// taps are staged once, and the NEXT tile's input window and epilogue operands are requested (unconditional, clamped
+// addresses; zeros selected afterwards) before the current tile's MFMAs and epilogue, then written to LDS when the
+// current tile is done -- the load round trip hides behind the previous tile's work.
+// ---------------------------------------------------------------------------------------
+template <int CC, int TM, bool RES, bool ACCU>
+__global__ __launch_bounds__(256) void conv_narrow_f16_kernel(ConvArgs a, int rows_win, int ntiles) {
+  typedef _Float16 T;
+  typedef h8 F;
+  typedef h4 T4;
+  constexpr int G = 8, KC = 16, CT = 32 * TM, TT = 256, NT = 256, TN = 2, WN = 4;
+  constexpr int LDX = CC + G, VPR = CC / G;
+  constexpr int XB = (306 * VPR + NT - 1) / NT;
+  constexpr int LDO = CT + 4, PR = TN * 32, IPR = CT / 4, NI = PR * IPR / NT;   // 64 rows per pass
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* xs = (T*)smem;                                   // [rows_win][LDX]; the epilogue's fp32 [PR][LDO] tile aliases it
+  T* ws = xs + (size_t)rows_win * LDX;                // [taps][CT][LDX], staged once
+  float* os = (float*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const T* __restrict__ x = (const T*)a.x;
+  const T* __restrict__ w = (const T*)a.w;
+  const int total = rows_win * VPR;
+  const bool vec_ok = ((a.ldy & 3) == 0) && ((a.y_col0 & 3) == 0) && ((a.ldr & 3) == 0);
+  const int ecg = tid % IPR, ec = 4 * ecg;
+  const int env = max(0, min(4, a.Cout - ec));
+  f4 ebias = (f4){0.f, 0.f, 0.f, 0.f};
+  if (a.bias) for (int j = 0; j < env; ++j) ebias[j] = a.bias[ec + j];
+  // ---- all taps' weights, once per workgroup
+  {
+    const int totw = a.taps * CT * VPR;
+    for (int v = tid; v < totw; v += NT) {
+      const int tap = v / (CT * VPR), rem = v - tap * (CT * VPR);
+      const int row = rem / VPR, col = rem - row * VPR;
+      F val = zfrag<F>();
+      if (row < a.Cout) val = *(const F*)(w + (long long)row * a.ldw + (long long)tap * a.Cin + col * G);
+      *(F*)(ws + ((size_t)tap * CT + row) * LDX + col * G) = val;
+    }
+  }
+  // window of tile `tile` -> registers: clamped (always valid) addresses, zero rows outside the sequence selected after
+  auto load_window = [&](int tile, F* regs) {
+    const int win_start = tile * TT - a.pad;
+#pragma unroll
+    for (int i = 0; i < XB; ++i) {
+      const int v = min(tid + i * NT, total - 1);
+      const int row = v / VPR, col = v - row * VPR;
+      const int ti = win_start + row;
+      const F val = *(const F*)(x + (long long)min(max(ti, 0), a.T_in - 1) * a.ldx + col * G);
+      regs[i] = (ti >= 0 && ti < a.T_in) ? val : zfrag<F>();
+    }
+  };
+  auto store_window = [&](const F* regs) {
+#pragma unroll
+    for (int i = 0; i < XB; ++i) {
+      const int v = tid + i * NT;
+      if (v < total) {
+        const int row = v / VPR, col = v - row * VPR;
+        F val = regs[i];
+        if (a.pre_act == ACT_LRELU) val = lrelu_l(val, a.pre_slope);
+        else if (a.pre_act == ACT_RELU) val = relu_l(val);
+        *(F*)(xs + (size_t)row * LDX + col * G) = val;
+      }
+    }
+  };
+  int tile = blockIdx.x;
+  {
+    F first[XB];
+    load_window(min(tile, ntiles - 1), first);
+    store_window(first);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int t0 = tile * TT;
+    // ---- requests for the NEXT tile's window and THIS tile's epilogue operands go out first
+    F nxt[XB];
+    load_window(min(tile + (int)gridDim.x, ntiles - 1), nxt);
+    T4 rv[RES ? WN * NI : 1], yv[ACCU ? WN * NI : 1];
+#pragma unroll
+    for (int q = 0; q < ((RES || ACCU) ? WN * NI : 0); ++q) {
+      const int pass = q / NI, e = q - pass * NI;
+      const int t = min(t0 + pass * PR + (tid + e * NT) / IPR, a.T_out - 1);
+      const int cc = min(ec, max(a.Cout - 4, 0));          // clamped channel group: loads stay in bounds; masked by env at use
+      if (RES) rv[q] = *(const T4*)((const T*)a.res + (long long)t * a.ldr + cc);
+      if (ACCU) yv[q] = *(const T4*)((const T*)a.y + (long long)t * a.ldy + a.y_col0 + cc);
+    }
+    f16v acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    for (int tap = 0; tap < a.taps; ++tap) {
+      const int shift = tap * a.dil;
+      const T* wb = ws + (size_t)tap * CT * LDX;
+#pragma unroll
+      for (int ks = 0; ks < CC / KC; ++ks) {
+        const int kk = ks * KC + G * h;
+        F af[TM], bf[TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) af[m] = *(const F*)(wb + (size_t)(m * 32 + r) * LDX + kk);
+#pragma unroll
+        for (int n = 0; n < TN; ++n) bf[n] = *(const F*)(xs + (size_t)((wn * TN + n) * 32 + r + shift) * LDX + kk);
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) mma32l(acc[m][n], af[m], bf[n]);
+      }
+    }
+    // ---- epilogue through LDS (whole channels-last rows per store), one wave column per pass
+#pragma unroll
+    for (int pass = 0; pass < WN; ++pass) {
+      __syncthreads();
+      if (wn == pass) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *(f4*)(os + (size_t)(n * 32 + r) * LDO + m * 32 + 8 * g + 4 * h) =
+                  (f4){acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < NI; ++e) {
+        const int q = pass * NI + e;
+        const int tl = (tid + e * NT) / IPR;
+        const int t = t0 + pass * PR + tl;
+        if (!(t < a.T_virt && t < a.T_out && env > 0)) continue;
+        const f4 av = *(const f4*)(os + (size_t)tl * LDO + 4 * ecg);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float u = av[j] + ebias[j];
+          if (RES) u += (float)rv[q][j];
+          u *= a.scale;
+          u = post_act_f(a.post_act, u);
+          if (ACCU) u += (float)yv[q][j];
+          v[j] = u;
+        }
+        T* yp = (T*)a.y + (long long)t * a.ldy + a.y_col0 + ec;
+        if (vec_ok && env == 4) *(T4*)yp = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+        else for (int j = 0; j < env; ++j) yp[j] = (T)v[j];
+      }
+    }
+    __syncthreads();                 // the fp32 tile (aliasing the window) has been read by every thread
+    store_window(nxt);
+    __syncthreads();
+  }
+}
+
+template <int CC, int TM>
+static int launch_narrow(const ConvArgs& a, int rows_win, hipStream_t s) {
+  const int ntiles = cdiv(a.T_virt, 256);
+  const size_t lds = ((size_t)rows_win + (size_t)a.taps * 32 * TM) * (CC + 8) * 2;
+  const int per_cu = lds <= 50 * 1024 ? 3 : (lds <= 78 * 1024 ? 2 : 1);
+  const int grid = std::min(ntiles, 256 * per_cu);
+  const bool res = a.res != nullptr, acc = a.accumulate != 0;
+#define GSV_NARROW(R, A)                                                                                                   \
+  do {                                                                                                                     \
+    auto kern = conv_narrow_f16_kernel<CC, TM, R, A>;                                                                         \
+    static bool set = false;                                                                                               \
+    if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, rows_win, ntiles);                                          \
+  } while (0)
+  if (res && acc) GSV_NARROW(true, true);
+  else if (res) GSV_NARROW(true, false);
+  else if (acc) GSV_NARROW(false, true);
+  else GSV_NARROW(false, false);
+#undef GSV_NARROW
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
 // returns 1 if the problem is not eligible (caller falls back to conv_gemm), 0 on success, <0 on error
 template <typename T> static int try_launch(const ConvArgs& a, hipStream_t s) {
   constexpr int G = DT<T>::G;
@@ -561,9 +742,28 @@ template <typename T> static int try_launch(const ConvArgs& a, hipStream_t s) {
     return 1;
   }
   if (a.Cout > 32) {
+    if (sizeof(T) == 2) {
+      // persistent variant for the 64-channel stage: all 11 tap slabs resident = 145 KB of LDS = ONE workgroup per CU, and
+      // then nothing overlaps the MFMA / epilogue phases: generator 17.2 vs 16.85 ms -> opt-in only (GSV_CONV_PERSIST64=1)
+      static const bool no_persist64 = getenv("GSV_CONV_PERSIST64") == nullptr;
+      const bool plain = a.ups_u == 0 && a.dil >= 1 && !a.out_f32 && !a.res_f32 && a.T_virt >= 16384 && a.T_out >= a.T_virt &&
+                         a.T_in >= 1 && (a.Cout % 4 == 0) && (!a.res || a.ldr % 4 == 0) && a.ldy % 4 == 0 && a.y_col0 % 4 == 0;
+      const size_t lds = ((size_t)rows + (size_t)a.taps * 64) * (64 + 8) * 2;
+      if (!no_persist64 && plain && a.Cin == 64 && a.Cout <= 64 && lds <= 160 * 1024) return launch_narrow<64, 2>(a, rows, s);
+    }
     if (a.Cin % 64 == 0 && fits<T, 64, 64>(rows)) return launch_inst<T, 2, 2, 1, 4, 64, false>(a, rows, lo, s);
     if (a.Cin % 32 == 0 && fits<T, 64, 32>(rows)) return launch_inst<T, 2, 2, 1, 4, 32, false>(a, rows, lo, s);
     return 1;
+  }
+  // persistent variant (fp16, one input chunk, plain stride-1 conv writing T-dtype rows): see conv_narrow_f16_kernel
+  if (sizeof(T) == 2) {
+    static const bool no_persist = getenv("GSV_CONV_NO_PERSIST") != nullptr;      // A/B switch
+    const bool plain = a.ups_u == 0 && a.dil >= 1 && !a.out_f32 && !a.res_f32 && a.T_virt >= 4096 && a.T_out >= a.T_virt &&
+                       a.T_in >= 1 && (a.Cout % 4 == 0) && (!a.res || a.ldr % 4 == 0) && a.ldy % 4 == 0 && a.y_col0 % 4 == 0;
+    if (!no_persist && plain && (a.Cin == 16 || a.Cin == 32)) {
+      const size_t lds = ((size_t)rows + (size_t)a.taps * 32) * (a.Cin + 8) * 2;
+      if (lds <= 64 * 1024) return a.Cin == 16 ? launch_narrow<16, 1>(a, rows, s) : launch_narrow<32, 1>(a, rows, s);
+    }
   }
   // narrow layers (HBM-bound): all taps' weights resident in LDS, no barrier in the tap loop; small
   // register / LDS footprint so that several workgroups per CU overlap their single load round trip

@@ -303,3 +303,24 @@ def test_flash_rel96_matches_reference_formula(T, heads):
         pb.scatter_add_(1, rel.clamp(0, 2 * W), torch.where(inband, p, torch.zeros((), device=DEV)))
         ref[:, h * D:(h + 1) * D] = o + pb @ rv
     assert (out.float() - ref).abs().max().item() <= 5e-3
+
+
+@pytest.mark.parametrize("C,k,dil,T", [(16, 11, 1, 5000), (16, 3, 5, 8192), (32, 7, 3, 4500), (32, 11, 5, 4096 + 77),
+                                       (64, 11, 5, 16384 + 100)])
+@pytest.mark.parametrize("mode", ["plain", "res", "res_acc"])
+def test_persistent_narrow_conv_matches_torch(C, k, dil, T, mode):
+    """persistent narrow-layer kernel (conv_narrow_f16_kernel: C = 16 / 32 / 64, long T, several tiles per workgroup with the
+    next window prefetched): leaky-relu on load, bias, residual, scale + accumulate, ragged last tile; fp16 vs torch fp32."""
+    torch.manual_seed(C + k + dil)
+    x = torch.randn(C, T)
+    w = torch.randn(C, C, k) / (C * k) ** 0.5
+    b = torch.randn(C)
+    res = torch.randn(C, T) if mode != "plain" else None
+    prev = torch.randn(C, T) if mode == "res_acc" else None
+    conv = F.conv1d(F.leaky_relu(x, 0.1).unsqueeze(0), w, b, padding=(k * dil - dil) // 2, dilation=dil)[0]
+    ref = conv + (res if res is not None else 0)
+    if prev is not None:
+        ref = prev + ref / 3.0
+    got = _conv(x, w, b, torch.float16, dil=dil, pre_lrelu=0.1, res=res, scale=(1.0 / 3.0 if prev is not None else 1.0),
+                accumulate=prev)
+    assert (got - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
