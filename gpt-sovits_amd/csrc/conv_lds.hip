@@ -95,13 +95,30 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
   // the wide tile (CT = 128) keeps only the residual in registers; its accumulate operand is fetched per
   // pass (that tile has ~19 us of MFMA work, the narrow ones have <2 us and must not stall at all)
   constexpr bool PRE_ACC = ACCU && CT < 128;
-  constexpr int NRV = RES ? WN * NI : 1, NYV = PRE_ACC ? WN * NI : 1;
+  // wide tile: the residual of ONE epilogue pass is resident (pass 0 from kernel entry, pass p+1 requested when pass p has
+  // been consumed); holding all WN passes (64 VGPRs beside 128 accumulator registers) spilled 272 B per lane
+  constexpr bool RES_LAZY = RES && CT >= 128;
+  constexpr int NRV = RES ? (RES_LAZY ? NI : WN * NI) : 1, NYV = PRE_ACC ? WN * NI : 1;
   T4 rv[NRV], yv[NYV];
+  auto load_res_pass = [&](int pass) {
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+      rv[e] = (T4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+      const int tl = (tid + e * NT) / IPR;
+      const int t = t0 + pass * PR + tl;
+      const int orow = a.ups_u > 0 ? t * a.ups_u + epp - a.ups_pad : t;
+      if (!(t < a.T_virt && env > 0 && orow >= 0 && orow < a.T_out)) continue;
+      const T* rp = (const T*)a.res + (long long)orow * a.ldr + eoc;
+      if (vec_ok && env == 4) rv[e] = *(const T4*)rp;
+      else for (int j = 0; j < env; ++j) rv[e][j] = rp[j];
+    }
+  };
   rv[0] = (T4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
   yv[0] = rv[0];
+  if (RES_LAZY) load_res_pass(0);
 #pragma unroll
-  for (int q = 0; q < ((RES || PRE_ACC) ? WN * NI : 0); ++q) {
-    if (RES) rv[q] = (T4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+  for (int q = 0; q < (((RES && !RES_LAZY) || PRE_ACC) ? WN * NI : 0); ++q) {
+    if (RES && !RES_LAZY) rv[q] = (T4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
     if (PRE_ACC) yv[q] = (T4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
     const int pass = q / NI, e = q - pass * NI;
     const int tl = (tid + e * NT) / IPR;
@@ -109,7 +126,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
     const int orow = a.ups_u > 0 ? t * a.ups_u + epp - a.ups_pad : t;
     const bool ok = t < a.T_virt && env > 0 && orow >= 0 && orow < a.T_out;
     if (!ok) continue;
-    if (RES) {
+    if (RES && !RES_LAZY) {
       const T* rp = (const T*)a.res + (long long)orow * a.ldr + eoc;
       if (vec_ok && env == 4) rv[q] = *(const T4*)rp;
       else for (int j = 0; j < env; ++j) rv[q][j] = rp[j];
@@ -278,7 +295,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float u = av[j] + ebias[j];
-        if (RES) u += to_f(rv[q][j]);
+        if (RES) u += to_f(rv[RES_LAZY ? e : q][j]);
         u *= a.scale;
         u = post_act_f(a.post_act, u);
         if (PRE_ACC) u += to_f(yv[q][j]);
@@ -297,6 +314,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
         else for (int j = 0; j < env; ++j) yp[j] = (T)v[j];
       }
     }
+    if (RES_LAZY && pass + 1 < WN) load_res_pass(pass + 1);
   }
 }
 
