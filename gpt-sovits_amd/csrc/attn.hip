@@ -8,10 +8,11 @@
 // running an online softmax over its chunks, and one LDS combine at the end.
 //
 // MFMA operand trick (no LDS transpose of P): scores are computed TRANSPOSED, S^T = K Q^T with mfma_f32_16x16x32_f16
-// (A = 16 keys x 32 d, B = Q^T), so a lane holds, for its query q = lane & 15, the keys {4g..4g+3} of two 16-key tiles
-// (g = lane >> 4).  Those 8 probabilities ARE a valid B operand (k-slot (g, j)) of the second product
-// O^T = V^T P^T once V^T's A operand uses the same key <-> k-slot permutation, i.e. two 8-byte loads from the
-// pre-transposed V (vt_kernel below).  The running max / sum / rescale factors of query q then live in the lanes that
+// (A = 16 keys x 32 d, B = Q^T), so a lane holds, for its query q = lane & 15, MFMA rows {4g..4g+3} of two 16-row score
+// tiles (g = lane >> 4).  The K rows are loaded PERMUTED (row 4g'+i of tile a = key 8g'+i, of tile b = key 8g'+4+i), so
+// those 8 values are the 8 consecutive keys 8g..8g+7 of the 32-key chunk, and they ARE a valid B operand (k-slot (g, j))
+// of the second product O^T = V^T P^T whose A operand is then ONE aligned 16-byte load per d-tile from the
+// pre-transposed V (vt_kernel below): fragment loads are what these kernels are bound by.  The running max / sum / rescale factors of query q then live in the lanes that
 // hold O^T[.][q]: no cross-lane traffic except two xor-shuffles per reduction.
 #include <stdlib.h>
 
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(256) void flash_attn64_f16_kernel(const _Float16* _
     qf1[t] = *(const h8*)(qp + 32);
   }
   const _Float16* kh = k + head * 64 + g * 8;
-  const _Float16* vh = vt + (long long)head * 64 * ldv + (long long)r * ldv + 4 * g;
+  const _Float16* vh = vt + (long long)head * 64 * ldv + (long long)r * ldv + 8 * g;
+  const int kra = 8 * (r >> 2) + (r & 3);           // MFMA row r of score tile a <-> key offset (tile b: + 4): see header
   f4 o[QT][4];
   float m[QT], l[QT];
 #pragma unroll
@@ -98,26 +100,18 @@ __global__ __launch_bounds__(256) void flash_attn64_f16_kernel(const _Float16* _
   // Two operand sets, used alternately by a loop unrolled by two: with ONE set the prefetched registers have to be
   // copied into the loop-carried ones at the back edge, and that copy waits for vmcnt(0) -- the prefetch then hides
   // nothing (seen in the ISA: vmcnt(12) ... vmcnt(0) inside one trip).
-  struct KV { h8 ka0, ka1, kb0, kb1; h4 va[4], vb[4]; };
+  struct KV { h8 ka0, ka1, kb0, kb1; h8 v[4]; };
   const int lastc = nchunks - 1;
   auto fetch = [&](KV& f, int c) {
     const int key0 = c << 5;
-    const _Float16* pa = kh + (long long)min(key0 + r, T - 1) * ldk;
-    const _Float16* pb = kh + (long long)min(key0 + 16 + r, T - 1) * ldk;
+    const _Float16* pa = kh + (long long)min(key0 + kra, T - 1) * ldk;
+    const _Float16* pb = kh + (long long)min(key0 + kra + 4, T - 1) * ldk;
     f.ka0 = *(const h8*)pa; f.ka1 = *(const h8*)(pa + 32); f.kb0 = *(const h8*)pb; f.kb1 = *(const h8*)(pb + 32);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const _Float16* pv = vh + (long long)(d * 16) * ldv + key0;
-      f.va[d] = *(const h4*)pv;
-      f.vb[d] = *(const h4*)(pv + 16);
-    }
+    for (int d = 0; d < 4; ++d) f.v[d] = *(const h8*)(vh + (long long)(d * 16) * ldv + key0);
   };
   auto process = [&](const KV& f, int c, bool valid) {
     const int key0 = c << 5;
-    h8 av[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-      av[d] = (h8){f.va[d][0], f.va[d][1], f.va[d][2], f.va[d][3], f.vb[d][0], f.vb[d][1], f.vb[d][2], f.vb[d][3]};
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       f4 sa = (f4){0.f, 0.f, 0.f, 0.f}, sb = sa;
@@ -126,9 +120,9 @@ __global__ __launch_bounds__(256) void flash_attn64_f16_kernel(const _Float16* _
       float p[8];
       float mx = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        p[i] = (valid && key0 + 4 * g + i < T) ? sa[i] * scale : -INFINITY;
-        p[4 + i] = (valid && key0 + 16 + 4 * g + i < T) ? sb[i] * scale : -INFINITY;
+      for (int i = 0; i < 4; ++i) {                  // lane (q = r, g) holds the 8 CONSECUTIVE keys key0 + 8g .. + 7
+        p[i] = (valid && key0 + 8 * g + i < T) ? sa[i] * scale : -INFINITY;
+        p[4 + i] = (valid && key0 + 8 * g + 4 + i < T) ? sb[i] * scale : -INFINITY;
         mx = fmaxf(mx, fmaxf(p[i], p[4 + i]));
       }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -146,7 +140,7 @@ __global__ __launch_bounds__(256) void flash_attn64_f16_kernel(const _Float16* _
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         o[t][d] *= alpha;
-        o[t][d] = mma16(av[d], pf, o[t][d]);        // O^T[d*16 + 4g + i][q = 16t + r]
+        o[t][d] = mma16(f.v[d], pf, o[t][d]);       // O^T[d*16 + 4g + i][q = 16t + r]
       }
     }
   };
@@ -271,7 +265,8 @@ __global__ __launch_bounds__(256) void flash_rel96_f16_kernel(const _Float16* __
   }
   __syncthreads();
   const _Float16* kh = k + head * D + g * 8;
-  const _Float16* vh = vt + (long long)head * D * ldv + (long long)r * ldv + 4 * g;
+  const _Float16* vh = vt + (long long)head * D * ldv + (long long)r * ldv + 8 * g;
+  const int kra = 8 * (r >> 2) + (r & 3);
   f4 o[QT][DT];
   float m[QT], l[QT];
 #pragma unroll
@@ -281,25 +276,18 @@ __global__ __launch_bounds__(256) void flash_rel96_f16_kernel(const _Float16* __
     for (int d = 0; d < DT; ++d) o[t][d] = (f4){0.f, 0.f, 0.f, 0.f};
   }
   const int nchunks = (T + 31) >> 5, lastc = nchunks - 1;
-  struct KV { h8 ka[KS], kb[KS]; h4 va[DT], vb[DT]; };
+  struct KV { h8 ka[KS], kb[KS]; h8 v[DT]; };
   auto fetch = [&](KV& f, int c) {
     const int key0 = c << 5;
-    const _Float16* pa = kh + (long long)min(key0 + r, T - 1) * ldk;
-    const _Float16* pb = kh + (long long)min(key0 + 16 + r, T - 1) * ldk;
+    const _Float16* pa = kh + (long long)min(key0 + kra, T - 1) * ldk;
+    const _Float16* pb = kh + (long long)min(key0 + kra + 4, T - 1) * ldk;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) { f.ka[ks] = *(const h8*)(pa + 32 * ks); f.kb[ks] = *(const h8*)(pb + 32 * ks); }
 #pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      const _Float16* pv = vh + (long long)(d * 16) * ldv + key0;
-      f.va[d] = *(const h4*)pv;
-      f.vb[d] = *(const h4*)(pv + 16);
-    }
+    for (int d = 0; d < DT; ++d) f.v[d] = *(const h8*)(vh + (long long)(d * 16) * ldv + key0);
   };
   auto process = [&](const KV& f, int c, bool valid) {
     const int key0 = c << 5;
-    h8 av[DT];
-#pragma unroll
-    for (int d = 0; d < DT; ++d) av[d] = (h8){f.va[d][0], f.va[d][1], f.va[d][2], f.va[d][3], f.vb[d][0], f.vb[d][1], f.vb[d][2], f.vb[d][3]};
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       f4 sa = (f4){0.f, 0.f, 0.f, 0.f}, sb = sa;
@@ -308,15 +296,15 @@ __global__ __launch_bounds__(256) void flash_rel96_f16_kernel(const _Float16* __
       float p[8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        p[i] = (valid && key0 + 4 * g + i < T) ? sa[i] * scale : -INFINITY;
-        p[4 + i] = (valid && key0 + 16 + 4 * g + i < T) ? sb[i] * scale : -INFINITY;
+        p[i] = (valid && key0 + 8 * g + i < T) ? sa[i] * scale : -INFINITY;
+        p[4 + i] = (valid && key0 + 8 * g + 4 + i < T) ? sb[i] * scale : -INFINITY;
       }
       const int qt0 = q0 + 16 * t;
       if (valid && key0 + 31 >= qt0 - W && key0 <= qt0 + 15 + W) {      // wave-uniform: this chunk touches the diagonal band
         const int qi = qt0 + r;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int j = key0 + (i < 4 ? 4 * g + i : 16 + 4 * g + i - 4);
+          const int j = key0 + 8 * g + i;
           const int rp = j - qi + W;
           if (rp >= 0 && rp < NB && j < T && qi < T) {
             p[i] += Bias[(16 * t + r) * NB + rp];
@@ -342,7 +330,7 @@ __global__ __launch_bounds__(256) void flash_rel96_f16_kernel(const _Float16* __
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         o[t][d] *= alpha;
-        o[t][d] = mma16(av[d], pf, o[t][d]);
+        o[t][d] = mma16(f.v[d], pf, o[t][d]);
       }
     }
   };

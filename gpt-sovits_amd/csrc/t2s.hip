@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void prefill_flash32_f16_kernel(const _Float16
   for (int t = 0; t < QT; ++t)
     qf[t] = *(const h8*)(qkv + (long long)(row_off[b] + min(q0 + 16 * t + r, S - 1)) * 3 * d + h * 32 + g * 8);
   const _Float16* kb = kc + ((long long)b * H + h) * smax * 32 + g * 8;
-  const _Float16* vb = vt + (((long long)b * H + h) * 32 + r) * spad + 4 * g;
+  const _Float16* vb = vt + (((long long)b * H + h) * 32 + r) * spad + 8 * g;
+  const int kra = 8 * (r >> 2) + (r & 3);           // permuted K rows: the lane's 8 scores are 8 consecutive keys (attn.hip)
   f4 o[QT][2];
   float m[QT], l[QT];
 #pragma unroll
@@ -191,23 +192,16 @@ __global__ __launch_bounds__(256) void prefill_flash32_f16_kernel(const _Float16
   const int qlast = min(q0 + BQ, S) - 1;
   const int nk = qlast < X ? X : qlast + 1;          // workgroup-uniform bound of the key range
   const int nchunks = (nk + 31) >> 5, lastc = nchunks - 1;
-  struct KV { h8 ka, kb2; h4 va[2], vb2[2]; };
+  struct KV { h8 ka, kb2; h8 v[2]; };
   auto fetch = [&](KV& f, int c) {
     const int key0 = c << 5;
-    f.ka = *(const h8*)(kb + (long long)min(key0 + r, S - 1) * 32);
-    f.kb2 = *(const h8*)(kb + (long long)min(key0 + 16 + r, S - 1) * 32);
+    f.ka = *(const h8*)(kb + (long long)min(key0 + kra, S - 1) * 32);
+    f.kb2 = *(const h8*)(kb + (long long)min(key0 + kra + 4, S - 1) * 32);
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      f.va[dt] = *(const h4*)(vb + (long long)(dt * 16) * spad + key0);
-      f.vb2[dt] = *(const h4*)(vb + (long long)(dt * 16) * spad + key0 + 16);
-    }
+    for (int dt = 0; dt < 2; ++dt) f.v[dt] = *(const h8*)(vb + (long long)(dt * 16) * spad + key0);
   };
   auto process = [&](const KV& f, int c, bool valid) {
     const int key0 = c << 5;
-    h8 av[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-      av[dt] = (h8){f.va[dt][0], f.va[dt][1], f.va[dt][2], f.va[dt][3], f.vb2[dt][0], f.vb2[dt][1], f.vb2[dt][2], f.vb2[dt][3]};
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       const int qi = q0 + 16 * t + r;
@@ -219,8 +213,8 @@ __global__ __launch_bounds__(256) void prefill_flash32_f16_kernel(const _Float16
       float mx = -INFINITY;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        p[i] = (valid && key0 + 4 * g + i < lim) ? sa[i] * scale : -INFINITY;
-        p[4 + i] = (valid && key0 + 16 + 4 * g + i < lim) ? sb[i] * scale : -INFINITY;
+        p[i] = (valid && key0 + 8 * g + i < lim) ? sa[i] * scale : -INFINITY;
+        p[4 + i] = (valid && key0 + 8 * g + 4 + i < lim) ? sb[i] * scale : -INFINITY;
         mx = fmaxf(mx, fmaxf(p[i], p[4 + i]));
       }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -239,7 +233,7 @@ __global__ __launch_bounds__(256) void prefill_flash32_f16_kernel(const _Float16
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         o[t][dt] *= alpha;
-        o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[dt], pf, o[t][dt], 0, 0, 0);
+        o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.v[dt], pf, o[t][dt], 0, 0, 0);
       }
     }
   };
