@@ -562,12 +562,13 @@ template <typename T, int CT, int CC> static bool fits(int rows, int wslabs = 2)
 // addresses; zeros selected afterwards) before the current tile's MFMAs and epilogue, then written to LDS when the
 // current tile is done -- the load round trip hides behind the previous tile's work.
 // ---------------------------------------------------------------------------------------
-template <int CC, int TM, bool RES, bool ACCU>
-__global__ __launch_bounds__(256) void conv_narrow_f16_kernel(ConvArgs a, int rows_win, int ntiles) {
+template <int CC, int TM, int TN, int WN, bool RES, bool ACCU>
+__global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, int rows_win, int ntiles) {
   typedef _Float16 T;
   typedef h8 F;
   typedef h4 T4;
-  constexpr int G = 8, KC = 16, CT = 32 * TM, TT = 256, NT = 256, TN = 2, WN = 4;
+  constexpr int G = 8, KC = 16, CT = 32 * TM, TT = 32 * TN * WN, NT = 64 * WN;
+  static_assert(TT == 256, "tiles are 256 time steps");
   constexpr int LDX = CC + G, VPR = CC / G;
   constexpr int XB = (306 * VPR + NT - 1) / NT;
   constexpr int LDO = CT + 4, PR = TN * 32, IPR = CT / 4, NI = PR * IPR / NT;   // 64 rows per pass
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(256) void conv_narrow_f16_kernel(ConvArgs a, int ro
   }
 }
 
-template <int CC, int TM>
+template <int CC, int TM, int TN, int WN>
 static int launch_narrow(const ConvArgs& a, int rows_win, hipStream_t s) {
   const int ntiles = cdiv(a.T_virt, 256);
   const size_t lds = ((size_t)rows_win + (size_t)a.taps * 32 * TM) * (CC + 8) * 2;
@@ -718,10 +719,10 @@ static int launch_narrow(const ConvArgs& a, int rows_win, hipStream_t s) {
   const bool res = a.res != nullptr, acc = a.accumulate != 0;
 #define GSV_NARROW(R, A)                                                                                                   \
   do {                                                                                                                     \
-    auto kern = conv_narrow_f16_kernel<CC, TM, R, A>;                                                                         \
+    auto kern = conv_narrow_f16_kernel<CC, TM, TN, WN, R, A>;                                                                         \
     static bool set = false;                                                                                               \
     if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, rows_win, ntiles);                                          \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN), lds, s, a, rows_win, ntiles);                                          \
   } while (0)
   if (res && acc) GSV_NARROW(true, true);
   else if (res) GSV_NARROW(true, false);
@@ -761,13 +762,13 @@ template <typename T> static int try_launch(const ConvArgs& a, hipStream_t s) {
   }
   if (a.Cout > 32) {
     if (sizeof(T) == 2) {
-      // persistent variant for the 64-channel stage: all 11 tap slabs resident = 145 KB of LDS = ONE workgroup per CU, and
-      // then nothing overlaps the MFMA / epilogue phases: generator 17.2 vs 16.85 ms -> opt-in only (GSV_CONV_PERSIST64=1)
-      static const bool no_persist64 = getenv("GSV_CONV_PERSIST64") == nullptr;
+      // persistent variant for the 64-channel stage: all 11 tap slabs resident = 145 KB of LDS = ONE workgroup per CU; run
+      // with 8 waves (2 per SIMD, 32 columns each) so one wave's MFMAs overlap another's LDS reads
+      static const bool no_persist64 = getenv("GSV_CONV_NO_PERSIST") != nullptr || getenv("GSV_CONV_NO_PERSIST64") != nullptr;
       const bool plain = a.ups_u == 0 && a.dil >= 1 && !a.out_f32 && !a.res_f32 && a.T_virt >= 16384 && a.T_out >= a.T_virt &&
                          a.T_in >= 1 && (a.Cout % 4 == 0) && (!a.res || a.ldr % 4 == 0) && a.ldy % 4 == 0 && a.y_col0 % 4 == 0;
       const size_t lds = ((size_t)rows + (size_t)a.taps * 64) * (64 + 8) * 2;
-      if (!no_persist64 && plain && a.Cin == 64 && a.Cout <= 64 && lds <= 160 * 1024) return launch_narrow<64, 2>(a, rows, s);
+      if (!no_persist64 && plain && a.Cin == 64 && a.Cout <= 64 && lds <= 160 * 1024) return launch_narrow<64, 2, 1, 8>(a, rows, s);
     }
     if (a.Cin % 64 == 0 && fits<T, 64, 64>(rows)) return launch_inst<T, 2, 2, 1, 4, 64, false>(a, rows, lo, s);
     if (a.Cin % 32 == 0 && fits<T, 64, 32>(rows)) return launch_inst<T, 2, 2, 1, 4, 32, false>(a, rows, lo, s);
@@ -780,7 +781,7 @@ template <typename T> static int try_launch(const ConvArgs& a, hipStream_t s) {
                        a.T_in >= 1 && (a.Cout % 4 == 0) && (!a.res || a.ldr % 4 == 0) && a.ldy % 4 == 0 && a.y_col0 % 4 == 0;
     if (!no_persist && plain && (a.Cin == 16 || a.Cin == 32)) {
       const size_t lds = ((size_t)rows + (size_t)a.taps * 32) * (a.Cin + 8) * 2;
-      if (lds <= 64 * 1024) return a.Cin == 16 ? launch_narrow<16, 1>(a, rows, s) : launch_narrow<32, 1>(a, rows, s);
+      if (lds <= 64 * 1024) return a.Cin == 16 ? launch_narrow<16, 1, 2, 4>(a, rows, s) : launch_narrow<32, 1, 2, 4>(a, rows, s);
     }
   }
   // narrow layers (HBM-bound): all taps' weights resident in LDS, no barrier in the tap loop; small
