@@ -699,9 +699,14 @@ __global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, in
           if (ACCU) u += (float)yv[q][j];
           v[j] = u;
         }
-        T* yp = (T*)a.y + (long long)t * a.ldy + a.y_col0 + ec;
-        if (vec_ok && env == 4) *(T4*)yp = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-        else for (int j = 0; j < env; ++j) yp[j] = (T)v[j];
+        if (a.out_f32) {                 // conv_post: one fp32 output channel
+          float* yp = (float*)a.y + (long long)t * a.ldy + a.y_col0 + ec;
+          for (int j = 0; j < env; ++j) yp[j] = v[j];
+        } else {
+          T* yp = (T*)a.y + (long long)t * a.ldy + a.y_col0 + ec;
+          if (vec_ok && env == 4) *(T4*)yp = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+          else for (int j = 0; j < env; ++j) yp[j] = (T)v[j];
+        }
       }
     }
     __syncthreads();                 // the fp32 tile (aliasing the window) has been read by every thread
@@ -777,8 +782,10 @@ template <typename T> static int try_launch(const ConvArgs& a, hipStream_t s) {
   // persistent variant (fp16, one input chunk, plain stride-1 conv writing T-dtype rows): see conv_narrow_f16_kernel
   if (sizeof(T) == 2) {
     static const bool no_persist = getenv("GSV_CONV_NO_PERSIST") != nullptr;      // A/B switch
-    const bool plain = a.ups_u == 0 && a.dil >= 1 && !a.out_f32 && !a.res_f32 && a.T_virt >= 4096 && a.T_out >= a.T_virt &&
-                       a.T_in >= 1 && (a.Cout % 4 == 0) && (!a.res || a.ldr % 4 == 0) && a.ldy % 4 == 0 && a.y_col0 % 4 == 0;
+    const bool epi_free = !a.res && !a.accumulate;       // no vector operand loads: any Cout / fp32 output (conv_post) is fine
+    const bool plain = a.ups_u == 0 && a.dil >= 1 && a.T_virt >= 4096 && a.T_out >= a.T_virt && a.T_in >= 1 &&
+                       (epi_free || (!a.out_f32 && !a.res_f32 && a.Cout % 4 == 0 && (!a.res || a.ldr % 4 == 0) &&
+                                     a.ldy % 4 == 0 && a.y_col0 % 4 == 0));
     if (!no_persist && plain && (a.Cin == 16 || a.Cin == 32)) {
       const size_t lds = ((size_t)rows + (size_t)a.taps * 32) * (a.Cin + 8) * 2;
       if (lds <= 64 * 1024) return a.Cin == 16 ? launch_narrow<16, 1, 2, 4>(a, rows, s) : launch_narrow<32, 1, 2, 4>(a, rows, s);

@@ -324,3 +324,23 @@ def test_persistent_narrow_conv_matches_torch(C, k, dil, T, mode):
     got = _conv(x, w, b, torch.float16, dil=dil, pre_lrelu=0.1, res=res, scale=(1.0 / 3.0 if prev is not None else 1.0),
                 accumulate=prev)
     assert (got - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_persistent_narrow_conv_single_fp32_output_channel():
+    """the generator's conv_post shape on the persistent kernel: 16 -> 1 channels, k = 7, leaky-relu(0.01) on load, tanh,
+    fp32 output (reference module/models.py:467-470)."""
+    from gsv import _lib
+    _lib.init(0)
+    torch.manual_seed(5)
+    Cin, k, T = 16, 7, 6000
+    x = torch.randn(Cin, T)
+    w = torch.randn(1, Cin, k) / (Cin * k) ** 0.5
+    ref = torch.tanh(F.conv1d(F.leaky_relu(x, 0.01).unsqueeze(0), w, None, padding=3)[0])
+    xd = x.t().contiguous().to(DEV, torch.float16)
+    wp = w.permute(0, 2, 1).reshape(1, k * Cin).contiguous().to(DEV, torch.float16)
+    y = torch.zeros(T, 1, device=DEV, dtype=torch.float32)
+    d = _lib.ConvDesc(xd.data_ptr(), wp.data_ptr(), None, y.data_ptr(), None, T, T, Cin, 1, k, 1, 1, 3, 3, 0.01, 2, 1.0, 0, 1, 0, 0,
+                      0, 0, 0, 0, 0, 0, 0, None)
+    _lib.check(_lib.lib().gsv_op_conv1d(C.byref(d), 1, None))
+    torch.cuda.synchronize()
+    assert (y.cpu().t() - ref).abs().max().item() < 5e-3
