@@ -539,6 +539,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   // allocated to smax, so the addresses are valid and groups beyond kv_len are simply masked.
   // This takes the kv_len -> K/V dependency off the critical path (prompt + text is always longer
   // than SPEC*4*KPI keys in practice, so nothing extra is streamed).
+  // The K/V stream (440 MB per step at the benchmark shape, read exactly once per step) is loaded NON-TEMPORAL so that it
+  // does not evict the 152 MB of decoder weights from the 256 MB Infinity Cache between steps (GSV_KV_TEMPORAL=1 at build
+  // time restores plain loads for A/B).
+#ifdef GSV_KV_TEMPORAL
+#define KVLOAD(p) (*(const F*)(p))
+#else
+#define KVLOAD(p) __builtin_nontemporal_load((const F*)(p))
+#endif
   constexpr int SPEC = 3;
   const F qv = *(const F*)(q + (long long)b * d + h * HD + part * G);
   F ksp[SPEC], vsp[SPEC];
@@ -546,8 +554,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   for (int i = 0; i < SPEC; ++i) {
     const int j = (wave + 4 * i) * KPI + slot;
     if (j < smax) {
-      ksp[i] = *(const F*)(kb + (long long)j * HD + part * G);
-      vsp[i] = *(const F*)(vb + (long long)j * HD + part * G);
+      ksp[i] = KVLOAD(kb + (long long)j * HD + part * G);
+      vsp[i] = KVLOAD(vb + (long long)j * HD + part * G);
     } else {
 #pragma unroll
       for (int e = 0; e < G; ++e) { ksp[i][e] = 0; vsp[i][e] = 0; }
@@ -588,8 +596,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   for (int i = 0; i < NEXT; ++i) {
     const int j = (wave + 4 * (SPEC + i)) * KPI + slot;
     if (j < n) {
-      kn[i] = *(const F*)(kb + (long long)j * HD + part * G);
-      vn[i] = *(const F*)(vb + (long long)j * HD + part * G);
+      kn[i] = KVLOAD(kb + (long long)j * HD + part * G);
+      vn[i] = KVLOAD(vb + (long long)j * HD + part * G);
     } else {
 #pragma unroll
       for (int e = 0; e < G; ++e) { kn[i][e] = 0; vn[i][e] = 0; }
@@ -605,8 +613,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     const bool ok = j < n;
     F kv, vv;
     if (ok) {
-      kv = *(const F*)(kb + (long long)j * HD + part * G);
-      vv = *(const F*)(vb + (long long)j * HD + part * G);
+      kv = KVLOAD(kb + (long long)j * HD + part * G);
+      vv = KVLOAD(vb + (long long)j * HD + part * G);
     } else {
 #pragma unroll
       for (int i = 0; i < G; ++i) { kv[i] = 0; vv[i] = 0; }
@@ -642,6 +650,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     const float v = s_acc[0][e] + s_acc[1][e] + s_acc[2][e] + s_acc[3][e];
     out[(long long)b * d + h * HD + e] = (T)(v / L);
   }
+#undef KVLOAD
 }
 
 // ---------------------------------------------------------------------------------------
