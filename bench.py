@@ -163,8 +163,12 @@ def main():
     for _ in range(args.steps):
         ts = time.perf_counter()
         out = step()
+        t_run = time.perf_counter() - ts
         torch.cuda.synchronize()
         times.append(time.perf_counter() - ts)
+        if rank == 0 and os.environ.get("GSV_BENCH_TRACE"):
+            log("   trace: sh.run %.1f ms, trailing sync %.1f ms, synth inside %.1f ms" % (1e3 * t_run, 1e3 * (times[-1] - t_run),
+                                                                                      1e3 * getattr(sh, "last_synth_s", 0.0)))
         if rank == 0:
             log("step %d: %.1f ms, stages (text, to_batch, AR, SoVITS, post) = %s" % (len(times) - 1, 1e3 * times[-1],
                 ", ".join("%.1f" % (1e3 * v) for v in list(tts.last_timing) + [getattr(tts, "last_postprocess_s", 0.0)])))

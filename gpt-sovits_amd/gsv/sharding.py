@@ -84,7 +84,10 @@ class ShardedSynthesizer:
             segments = unpack_segments(wire)
         shares = deal_contiguous([len(s["norm_text"]) for s in segments], self.world)
         mine = shares[self.rank]
+        import time as _time
+        _t0 = _time.perf_counter()
         audio, frag_lens = self.synth([segments[i] for i in mine]) if mine else (np.zeros(0, dtype=np.int16), [])
+        self.last_synth_s = _time.perf_counter() - _t0
         if self.world == 1:
             a = audio.cpu().numpy() if torch.is_tensor(audio) else audio
             assert a.dtype == np.int16 and sum(frag_lens) == a.size
