@@ -125,6 +125,8 @@ struct ConvArgs {
   long long xz = 0, wz = 0, yz = 0, rz = 0;  // batch strides in elements
   int bz = 0;                                // batch stride of bias / gate (grouped convs)
   int xcd_order = 0;                         // set by the launcher: 1 = decode tile ids through xcd_virtual_id
+  int w_nt = 0;                              // weights are loaded non-temporal (streamed once per step: keep them out of the
+                                             // Infinity Cache so that OTHER layers' weights stay resident), GEMM paths only
 };
 int launch_conv_gemm(int dtype, const ConvArgs& a, hipStream_t s);
 // split-K-in-workgroup streaming GEMM for under-filled grids (gemm_sk.hip): 0 = launched, 1 = not eligible, <0 = error

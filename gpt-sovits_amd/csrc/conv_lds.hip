@@ -324,7 +324,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
 // operands double-buffered in LDS through registers: the loads of K-chunk c+1 are in flight while
 // chunk c feeds 16 MFMAs per wave, one barrier per chunk; ~74 KB of LDS -> two workgroups per CU.
 // ---------------------------------------------------------------------------------------
-template <typename T, bool RES>
+template <typename T, bool RES, bool WNT = false>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
   typedef typename FragL<T>::type F;
   constexpr int G = DT<T>::G, KC = 2 * G;
@@ -395,7 +395,8 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
       const int kk = k0 + col * G;
       const int t = t0 + row, co = cout0 + row;
       xr[i] = (t < a.T_in && kk < K) ? *(const F*)(x + (long long)t * a.ldx + kk) : zfrag<F>();
-      wr[i] = (co < a.Cout && kk < K) ? *(const F*)(w + (long long)co * a.ldw + kk) : zfrag<F>();
+      if (WNT) wr[i] = (co < a.Cout && kk < K) ? __builtin_nontemporal_load((const F*)(w + (long long)co * a.ldw + kk)) : zfrag<F>();
+      else wr[i] = (co < a.Cout && kk < K) ? *(const F*)(w + (long long)co * a.ldw + kk) : zfrag<F>();
     }
   };
   auto store_tiles = [&](int buf, F* xr, const F* wr) {
@@ -507,6 +508,11 @@ template <typename T> static int try_launch_gemm(const ConvArgs& a, hipStream_t 
   b.xcd_order = xcd ? 1 : 0;
   if (a.res) {
     auto kern = gemm_lds_kernel<T, true>;
+    static bool set = false;
+    if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
+  } else if (a.w_nt) {
+    auto kern = gemm_lds_kernel<T, false, true>;
     static bool set = false;
     if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);

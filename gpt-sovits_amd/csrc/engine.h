@@ -67,6 +67,7 @@ struct ConvOpt {
   int ldy = 0, y_col0 = 0;
   const float* bias_override = nullptr; bool no_bias = false;
   const float* gate = nullptr;   // per-output-channel gate: y = ((W x + b) * gate + res) * scale
+  int w_nt = 0;                  // stream the weights non-temporal (ConvArgs::w_nt)
   int w_row0 = 0, cout = -1;   // use a row slice of the weight matrix
 };
 

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void gemm_sk_f16_kernel(ConvArgs a) {
 // slab (64 KB per step, two register sets + two LDS buffers = the next TWO slabs in flight under the current one).
 struct Slab { h8 a[8], b[8]; };
 
+template <bool WNT>
 __global__ __launch_bounds__(256) void gemm_t64_f16_kernel(ConvArgs a) {
   constexpr int LDO = 68;
   extern __shared__ float os[];                     // 2 x [A: 64 rows x 512 B][B: 64 rows x 512 B]; epilogue: [64 t][LDO] fp32
@@ -195,7 +196,10 @@ __global__ __launch_bounds__(256) void gemm_t64_f16_kernel(ConvArgs a) {
   auto load = [&](Slab& f, int c) {
     const int k0 = c << 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { f.a[i] = *(const h8*)(wp[i] + k0); f.b[i] = *(const h8*)(xp[i] + k0); }
+    for (int i = 0; i < 8; ++i) {
+      f.a[i] = WNT ? __builtin_nontemporal_load((const h8*)(wp[i] + k0)) : *(const h8*)(wp[i] + k0);
+      f.b[i] = *(const h8*)(xp[i] + k0);
+    }
   };
   auto stage = [&](const Slab& f, int buf) {
     char* base = lds + buf * 65536;
@@ -281,11 +285,13 @@ int launch_gemm_sk(int dtype, const ConvArgs& a, hipStream_t s) {
     static bool attr64 = false;
     const size_t lds64 = 131072;
     if (!attr64) {
-      GSV_HIP(hipFuncSetAttribute((const void*)gemm_t64_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
+      GSV_HIP(hipFuncSetAttribute((const void*)gemm_t64_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
+      GSV_HIP(hipFuncSetAttribute((const void*)gemm_t64_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
       attr64 = true;
     }
     dim3 grid64(cdiv(a.T_virt, 64), cdiv(a.Cout, 64));
-    hipLaunchKernelGGL(gemm_t64_f16_kernel, grid64, dim3(256), lds64, s, a);
+    if (a.w_nt) hipLaunchKernelGGL(gemm_t64_f16_kernel<true>, grid64, dim3(256), lds64, s, a);
+    else hipLaunchKernelGGL(gemm_t64_f16_kernel<false>, grid64, dim3(256), lds64, s, a);
     GSV_HIP(hipGetLastError());
     return 0;
   }

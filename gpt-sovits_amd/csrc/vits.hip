@@ -505,6 +505,7 @@ int conv(gsv_vits* h, hipStream_t s, const Conv& c, const void* x, int ldx, int 
   a.w = (const char*)c.w + (size_t)o.w_row0 * c.taps * c.cin * esz(h);
   a.bias = o.no_bias ? nullptr : (o.bias_override ? o.bias_override : (c.b ? c.b + (c.ups_u ? 0 : o.w_row0) : nullptr));
   a.gate = o.gate;
+  a.w_nt = o.w_nt;
   a.T_in = T_in; a.T_out = T_out; a.Cin = c.cin; a.Cout = cout; a.taps = c.taps;
   a.stride = o.stride; a.dil = o.dil;
   a.pad = o.pad >= 0 ? o.pad : (c.taps * o.dil - o.dil) / 2;
