@@ -1606,7 +1606,7 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
   hipGraphExec_t exec = nullptr;
   auto it = h->graphs.find(h->B);
   if (it != h->graphs.end()) exec = it->second;
-  else if (s != nullptr && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+  else if (s != nullptr && !getenv("GSV_T2S_NO_GRAPH") && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
     hipGraph_t graph;
     int rc = launch_step(h, s);
     hipError_t e = hipStreamEndCapture(s, &graph);
