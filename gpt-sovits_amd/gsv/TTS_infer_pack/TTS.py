@@ -515,7 +515,9 @@ class TTS:
                                             item["all_bert_features"], top_k=top_k, top_p=top_p, temperature=temperature,
                                             early_stop_num=self.configs.hz * max_sec, max_len=item["max_len"],
                                             repetition_penalty=repetition_penalty, seed=actual_seed + bi)
-                torch.cuda.synchronize(self.configs.device)
+                # stream-level wait only: the engine calls above already synchronised their own streams, and a DEVICE-wide
+                # synchronize intermittently stalls 20-30 ms on this ROCm build
+                torch.cuda.current_stream(self.configs.device).synchronize()
                 t4 = time.perf_counter()
                 t_34 += t4 - t3
                 if no_prompt:     # idx is reported as 0 and y holds only generated tokens (t2s_model.py:916-917)
@@ -557,7 +559,9 @@ class TTS:
                     for k, p in enumerate(pred):
                         frags.append(self.vits_model.decode(p.view(1, 1, -1), item["phones"][k].view(1, -1), refer,
                                                             speed=speed_factor, seed=actual_seed + bi, **sv_kw)[0, 0])
-                torch.cuda.synchronize(self.configs.device)
+                # stream-level wait only: the engine calls above already synchronised their own streams, and a DEVICE-wide
+                # synchronize intermittently stalls 20-30 ms on this ROCm build
+                torch.cuda.current_stream(self.configs.device).synchronize()
                 t5 = time.perf_counter()
                 t_45 += t5 - t4
                 if return_fragment:
