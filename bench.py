@@ -19,6 +19,7 @@ kind "port") on a bounded sample of the same workload on this box's host cores.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import statistics
@@ -129,10 +130,19 @@ def main():
                   split_bucket=True, parallel_infer=True, fragment_interval=0.3)
     tok_count = [0]
 
+    one_stream = None
+    if os.environ.get("GSV_BENCH_ONE_STREAM", "1") != "0":
+        # one HIP stream for both engines and the torch glue: no cross-stream event waits between the stages
+        one_stream = torch.cuda.Stream(device=dev)
+        tts.t2s_model.stream = one_stream
+        tts.vits_model.stream = one_stream
+
     def synth(segments):
         out = None
-        for sr, audio in tts.run(dict(params, segments=segments)):
-            out = audio
+        ctx = torch.cuda.stream(one_stream) if one_stream is not None else contextlib.nullcontext()
+        with ctx:
+            for sr, audio in tts.run(dict(params, segments=segments)):
+                out = audio
         tok_count[0] += tts.last_generated_tokens
         return out, list(tts.last_fragment_lengths)
 
