@@ -762,7 +762,8 @@ template <typename T> static int try_launch(const ConvArgs& a, hipStream_t s) {
     // (SoVITS 23.9 -> 23.2 ms per bench step; 64-step tiles for the smallest grids measured no further gain)
     static const bool no_half = getenv("GSV_CONV_NO_HALF_TILE") != nullptr;      // A/B switch
     const long long wgs256 = (long long)cdiv(a.T_virt, 256) * cdiv(a.Cout, 128);
-    if (!no_half && wgs256 < 192) {
+    static const bool half_always = getenv("GSV_CONV_HALF_ALWAYS") != nullptr;    // experiment switch
+    if (!no_half && (wgs256 < 192 || half_always)) {
       const int rows128 = 128 + span;
       if (a.Cin >= CCBIG && fits<T, 128, CCBIG>(rows128)) return launch_inst<T, 2, 2, 2, 2, CCBIG, false>(a, rows128, lo, s);
       if (a.Cin >= CCBIG / 2 && fits<T, 128, CCBIG / 2>(rows128)) return launch_inst<T, 2, 2, 2, 2, CCBIG / 2, false>(a, rows128, lo, s);
