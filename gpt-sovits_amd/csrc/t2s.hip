@@ -350,13 +350,8 @@ __global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs a) {
   // weight stream first: its HBM latency overlaps the LayerNorm prologue
   F af[NKS];
 #pragma unroll
-  for (int i = 0; i < NKS; ++i) {
-    if (wok) af[i] = *(const F*)(wrow + i * KS);
-    else {
-#pragma unroll
-      for (int e = 0; e < G; ++e) af[i][e] = 0;
-    }
-  }
+  for (int i = 0; i < NKS; ++i) af[i] = *(const F*)(wrow + i * KS);   // unconditional: wrow is clamped to row 0 when n0 + rowl >= N,
+                                                                       // and those output rows are never stored
 
   // epilogue operands (bias, residual, row state) are fetched now, not after the LDS combine, so the
   // kernel has one exposed memory round trip instead of two
