@@ -546,15 +546,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   const F qv = *(const F*)(q + (long long)b * d + h * HD + part * G);
   F ksp[SPEC], vsp[SPEC];
 #pragma unroll
+  // Every K/V load below is UNCONDITIONAL with a clamped key index (lanes past the end re-read the last valid row, which
+  // costs no extra traffic, and are masked in consume()): per-lane conditional loads were compiled as one exec-masked
+  // block per group with vmcnt(0) at each join, i.e. the NEXT groups were five dependent memory round trips.
   for (int i = 0; i < SPEC; ++i) {
-    const int j = (wave + 4 * i) * KPI + slot;
-    if (j < smax) {
-      ksp[i] = KVLOAD(kb + (long long)j * HD + part * G);
-      vsp[i] = KVLOAD(vb + (long long)j * HD + part * G);
-    } else {
-#pragma unroll
-      for (int e = 0; e < G; ++e) { ksp[i][e] = 0; vsp[i][e] = 0; }
-    }
+    const int j = min((wave + 4 * i) * KPI + slot, smax - 1);
+    ksp[i] = KVLOAD(kb + (long long)j * HD + part * G);
+    vsp[i] = KVLOAD(vb + (long long)j * HD + part * G);
   }
   if (!active[b]) return;
   const int n = min(kv_len[b] + 1, smax);
@@ -589,14 +587,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   F kn[NEXT], vn[NEXT];
 #pragma unroll
   for (int i = 0; i < NEXT; ++i) {
-    const int j = (wave + 4 * (SPEC + i)) * KPI + slot;
-    if (j < n) {
-      kn[i] = KVLOAD(kb + (long long)j * HD + part * G);
-      vn[i] = KVLOAD(vb + (long long)j * HD + part * G);
-    } else {
-#pragma unroll
-      for (int e = 0; e < G; ++e) { kn[i][e] = 0; vn[i][e] = 0; }
-    }
+    const int j = min((wave + 4 * (SPEC + i)) * KPI + slot, n - 1);
+    kn[i] = KVLOAD(kb + (long long)j * HD + part * G);
+    vn[i] = KVLOAD(vb + (long long)j * HD + part * G);
   }
 #pragma unroll
   for (int i = 0; i < SPEC; ++i) consume(ksp[i], vsp[i], (wave + 4 * i) * KPI + slot < n);
@@ -606,14 +599,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   for (int j0 = (wave + 4 * (SPEC + NEXT)) * KPI; j0 < n; j0 += 4 * KPI) {
     const int j = j0 + slot;
     const bool ok = j < n;
-    F kv, vv;
-    if (ok) {
-      kv = KVLOAD(kb + (long long)j * HD + part * G);
-      vv = KVLOAD(vb + (long long)j * HD + part * G);
-    } else {
-#pragma unroll
-      for (int i = 0; i < G; ++i) { kv[i] = 0; vv[i] = 0; }
-    }
+    const int jc = min(j, n - 1);
+    const F kv = KVLOAD(kb + (long long)jc * HD + part * G);
+    const F vv = KVLOAD(vb + (long long)jc * HD + part * G);
     consume(kv, vv, ok);
   }
   // combine: global max, rescale, sum over key slots (lanes with equal `part`) and waves
