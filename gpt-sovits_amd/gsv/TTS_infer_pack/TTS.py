@@ -329,7 +329,11 @@ class TTS:
         # (x * 32768).astype(int16): C-style truncation, +32768 wraps to -32768 exactly as numpy does on the
         # reference's host path; done on the device so only int16 crosses PCIe
         pcm = (wav * 32768).to(torch.int32).to(torch.int16)
-        return sr, pcm.cpu().numpy()
+        return sr, self._to_host(pcm)
+
+    def _to_host(self, t: torch.Tensor) -> np.ndarray:
+        from gsv.hostcopy import to_host
+        return to_host(t)
 
 
     # ---- v3 / v4 synthesis (reference TTS.py:1431-1637) -----------------------------------------

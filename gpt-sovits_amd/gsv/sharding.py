@@ -16,6 +16,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from gsv.hostcopy import to_host
+
 
 def deal_contiguous(lengths: Sequence[int], world: int) -> List[List[int]]:
     """Length-sort the items (stable) and give each rank one contiguous run of the sorted order, so a
@@ -89,7 +91,7 @@ class ShardedSynthesizer:
         audio, frag_lens = self.synth([segments[i] for i in mine]) if mine else (np.zeros(0, dtype=np.int16), [])
         self.last_synth_s = _time.perf_counter() - _t0
         if self.world == 1:
-            a = audio.cpu().numpy() if torch.is_tensor(audio) else audio
+            a = to_host(audio) if torch.is_tensor(audio) else audio
             assert a.dtype == np.int16 and sum(frag_lens) == a.size
             return _reorder([a], [frag_lens], shares, len(segments))
         if not torch.is_tensor(audio):
@@ -113,7 +115,7 @@ class ShardedSynthesizer:
             fbufs = [torch.zeros_like(fl) for _ in range(self.world)]
             dist.gather(pad, bufs, dst=0, group=self.group)
             dist.gather(fl, fbufs, dst=0, group=self.group)
-            arrays = [b.view(torch.int16)[: int(n.item())].cpu().numpy() for b, n in zip(bufs, all_n)]
+            arrays = [to_host(b.view(torch.int16)[: int(n.item())]) for b, n in zip(bufs, all_n)]
             lens = [f[: len(s)].cpu().tolist() for f, s in zip(fbufs, shares)]
             return _reorder(arrays, lens, shares, len(segments))
         dist.gather(pad, None, dst=0, group=self.group)
