@@ -28,6 +28,7 @@ import torch.nn.functional as F
 
 from ..AR.models.t2s_model import Text2SemanticDecoder
 from ..module.models import SynthesizerTrn, SynthesizerTrnV3
+from ..process_ckpt import load_sovits_new  # noqa: F401  (reference process_ckpt.py:129-138; re-exported)
 
 
 spec_min, spec_max = -12, 2          # reference TTS.py:55-56
@@ -597,16 +598,3 @@ class TTS:
             finally:
                 raise e
 
-
-def load_sovits_new(path: str) -> dict:
-    """Reference process_ckpt.py:129-138: newer SoVITS files replace the zip magic `PK` with a 2-byte
-    version code; put `PK` back and load with a non-executing loader."""
-    import io
-    with open(path, "rb") as f:
-        head = f.read(2)
-        rest = f.read()
-    if head != b"PK":
-        data = io.BytesIO(b"PK" + rest)
-    else:
-        data = io.BytesIO(head + rest)
-    return torch.load(data, map_location="cpu", weights_only=True)
