@@ -170,3 +170,48 @@ def test_prompt_free_naive_matches_reference(name):
                                    repetition_penalty=case["rep"], noise=nz)
     assert idx == 0
     assert y[0].cpu().tolist() == g.tolist()
+
+
+def test_capacity_limits_chunking_arena_bound_and_loud_errors():
+    """maximum sizes: (1) a batch larger than max_batch is decoded in max_batch chunks and, row independence under greedy
+    fp32 decode, gives the same ids as one big engine; (2) when the K/V arena (max_seq) ends before early_stop_num the
+    run stops at the arena bound with every row reporting the same length; (3) an input that cannot fit raises
+    ValueError before anything is launched; (4) the C ABI refuses a batch above max_batch with an error code + message."""
+    import ctypes as C
+    from gsv import _lib
+    case = cases.T2S_CASES["t2s_small_greedy"]
+    cfg, sd, xs, berts, prompts, _ = cases.t2s_case_inputs(case)
+    dev = DEV
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, early_stop_num=case["early_stop"], repetition_penalty=case["rep"])
+    args = ([x.to(dev) for x in xs], None, prompts.to(dev), [b.to(dev) for b in berts])
+    big = _engine(cfg, sd, torch.float32, max_batch=8)
+    small = _engine(cfg, sd, torch.float32, max_batch=2)
+    assert len(xs) > 2
+    ya, ia = big.infer_panel_batch_infer(*args, **kw)
+    yb, ib = small.infer_panel_batch_infer(*args, **kw)
+    g = load_golden("t2s_small_greedy")
+    assert ia == g["idx"].tolist()
+    # chunks of 2 are padded to their own longest row; ids must still match the reference row by row
+    assert ib == ia and [t.tolist() for t in yb] == [t.tolist() for t in ya]
+
+    P = prompts.shape[1]
+    need = max(int(x.shape[0]) for x in xs) + P + 2
+    tight = _engine(cfg, sd, torch.float32, max_batch=8, max_seq=need + 5)
+    yt, it = tight.infer_panel_batch_infer(*args, top_k=1, top_p=1.0, temperature=1.0, early_stop_num=200,
+                                           repetition_penalty=case["rep"])
+    assert max(it) <= 5 and all(int(t.shape[0]) == P + n for t, n in zip(yt, it))
+    for a, b in zip(yt, ya):                                   # a prefix of the unconstrained run
+        n = min(a.shape[0], b.shape[0])
+        assert a[:n].tolist() == b[:n].tolist()
+
+    with pytest.raises(ValueError):
+        _engine(cfg, sd, torch.float32, max_batch=8, max_seq=need).infer_panel_batch_infer(*args, **kw)
+
+    # C ABI: B > max_batch
+    eng = small
+    phones = torch.cat([x for x in xs]).to(dev, torch.int32)
+    lens = (C.c_int32 * len(xs))(*[int(x.shape[0]) for x in xs])
+    pr = prompts.to(dev, torch.int32).contiguous()
+    rc = _lib.lib().gsv_t2s_prefill(eng._h, phones.data_ptr(), C.cast(lens, C.c_void_p), len(xs), None, pr.data_ptr(), P,
+                                    C.c_void_p(eng.stream.cuda_stream))
+    assert rc != 0 and b"batch" in _lib.lib().gsv_last_error().lower()
