@@ -595,14 +595,33 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   for (int i = 0; i < SPEC; ++i) consume(ksp[i], vsp[i], (wave + 4 * i) * KPI + slot < n);
 #pragma unroll
   for (int i = 0; i < NEXT; ++i) consume(kn[i], vn[i], (wave + 4 * (SPEC + i)) * KPI + slot < n);
-#pragma unroll 8
-  for (int j0 = (wave + 4 * (SPEC + NEXT)) * KPI; j0 < n; j0 += 4 * KPI) {
-    const int j = j0 + slot;
-    const bool ok = j < n;
-    const int jc = min(j, n - 1);
-    const F kv = KVLOAD(kb + (long long)jc * HD + part * G);
-    const F vv = KVLOAD(vb + (long long)jc * HD + part * G);
-    consume(kv, vv, ok);
+  // keys past the first (SPEC+NEXT) groups (long sequences): batches of TB groups, two register sets alternated so the
+  // next batch is in flight while the current one is consumed (all loads unconditional with a clamped key index).
+  {
+    constexpr int TB = 4, STR = 4 * KPI;
+    int j0 = (wave + 4 * (SPEC + NEXT)) * KPI;
+    if (j0 < n) {
+      F ka[TB], va[TB], kq[TB], vq[TB];
+      auto loadb = [&](F* kk, F* vv, int base) {
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+          const int jc = min(base + i * STR + slot, n - 1);
+          kk[i] = KVLOAD(kb + (long long)jc * HD + part * G);
+          vv[i] = KVLOAD(vb + (long long)jc * HD + part * G);
+        }
+      };
+      auto consb = [&](const F* kk, const F* vv, int base) {
+#pragma unroll
+        for (int i = 0; i < TB; ++i) consume(kk[i], vv[i], base + i * STR + slot < n);
+      };
+      loadb(ka, va, j0);
+      for (; j0 < n; j0 += 2 * TB * STR) {
+        loadb(kq, vq, j0 + TB * STR);
+        consb(ka, va, j0);
+        loadb(ka, va, j0 + 2 * TB * STR);
+        consb(kq, vq, j0 + TB * STR);
+      }
+    }
   }
   // combine: global max, rescale, sum over key slots (lanes with equal `part`) and waves
   __shared__ float s_m[4];
@@ -1697,6 +1716,22 @@ int gsv_t2s_debug_set_state(gsv_t2s_t* h, int B, int kv_len) {
   GSV_HIP(hipMemset(h->ybuf, 0, (size_t)B * h->cfg.dim * 4));
   GSV_HIP(hipMemset(h->kv, 0, (size_t)h->cfg.n_layer * 2 * h->kv_layer_stride * esz(h)));
   h->B = B;
+  return GSV_OK;
+}
+
+int gsv_op_decode_attn(const void* q, const void* kc, const void* vc, const int32_t* kv_len, const int32_t* active, int B, int H,
+                       int smax, int dtype, void* out, gsv_stream_t stream) {
+  GSV_REQUIRE(q && kc && vc && kv_len && active && out, "op_decode_attn: null pointer");
+  GSV_REQUIRE(B >= 1 && B <= 65535 && H >= 1 && smax >= 1, "op_decode_attn: bad shape B=%d H=%d smax=%d", B, H, smax);
+  GSV_REQUIRE(dtype == GSV_F16 || dtype == GSV_F32, "op_decode_attn: bad dtype %d", dtype);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == GSV_F16)
+    hipLaunchKernelGGL((decode_attn_kernel<_Float16, 32>), dim3(H, B), dim3(256), 0, s, (const _Float16*)q, (const _Float16*)kc,
+                       (const _Float16*)vc, kv_len, active, H, smax, (_Float16*)out);
+  else
+    hipLaunchKernelGGL((decode_attn_kernel<float, 32>), dim3(H, B), dim3(256), 0, s, (const float*)q, (const float*)kc,
+                       (const float*)vc, kv_len, active, H, smax, (float*)out);
+  GSV_HIP(hipGetLastError());
   return GSV_OK;
 }
 

@@ -103,6 +103,8 @@ _SIGS = {
     "gsv_op_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "gsv_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_float, C.c_int, C.c_void_p]),
+    "gsv_op_decode_attn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p, C.c_void_p]),
     "gsv_op_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                 C.POINTER(SamplingParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -247,6 +247,12 @@ int gsv_op_flash_attn64(const void* qkv, int T, int heads, float scale, void* vt
  * qkv [dev] f16 [T][3*heads*96], rel_k / rel_v [dev] fp32 [9][96], vt_scratch heads*96*ceil32(T) halfs, out f16 [T][heads*96] */
 int gsv_op_flash_rel96(const void* qkv, int T, int heads, float scale, const float* rel_k, const float* rel_v, void* vt_scratch,
                        void* out, gsv_stream_t stream);
+/* the AR decode-step attention alone (reference t2s_model.py:176-221, one query per row over its cached keys; head dim 32):
+ * q [dev] [B][H*32]; kc / vc [dev] [B][H][smax][32]; kv_len [dev] int32 [B]: row b attends to keys 0..kv_len[b] (the
+ * current token's K/V already stored at position kv_len[b]); active [dev] int32 [B] (0 = row skipped, out untouched);
+ * out [dev] [B][H*32].  dtype GSV_F16 / GSV_F32 applies to q, kc, vc, out. */
+int gsv_op_decode_attn(const void* q, const void* kc, const void* vc, const int32_t* kv_len, const int32_t* active, int B, int H,
+                       int smax, int dtype, void* out, gsv_stream_t stream);
 /* channels-last conv1d: x [T_in][Cin], w [Cout][taps*Cin] (tap-major, cin fastest), y [T_out][Cout] */
 int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream);
 /* y = LN(x (+res)) over the last dim C; all buffers of `dtype`, gamma/beta fp32 */

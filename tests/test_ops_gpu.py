@@ -344,3 +344,38 @@ def test_persistent_narrow_conv_single_fp32_output_channel():
     _lib.check(_lib.lib().gsv_op_conv1d(C.byref(d), 1, None))
     torch.cuda.synchronize()
     assert (y.cpu().t() - ref).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.float32, 2e-5)])
+def test_decode_attention_all_cache_lengths(dtype, tol):
+    """the AR decode-step attention kernel alone (reference t2s_model.py:176-221: softmax(q.K^T/sqrt(32)).V over the cached
+    keys) vs torch fp32 on the same (dtype-rounded) inputs, for cache lengths on every side of the kernel's phase
+    boundaries (speculative groups, second batch, pipelined tail: 1 key ... the reference's 1500-token limit), ragged per
+    row, one inactive row left untouched.  max-abs tolerance in the table (|out| <= 1)."""
+    import ctypes as C
+    from gsv import _lib
+    _lib.init(0)
+    torch.manual_seed(5)
+    H, HD, smax = 4, 32, 1536
+    lens = [0, 1, 15, 16, 63, 64, 191, 192, 255, 256, 257, 511, 512, 513, 640, 767, 1023, 1024, 1499, 1534]
+    B = len(lens) + 1
+    q = torch.randn(B, H * HD, device=DEV).to(dtype)
+    kc = torch.randn(B, H, smax, HD, device=DEV).to(dtype)
+    vc = torch.randn(B, H, smax, HD, device=DEV).to(dtype)
+    kv_len = torch.tensor(lens + [100], dtype=torch.int32, device=DEV)
+    active = torch.ones(B, dtype=torch.int32, device=DEV)
+    active[-1] = 0
+    out = torch.full((B, H * HD), 7.0, device=DEV, dtype=dtype)
+    code = _lib.dtype_code(dtype)
+    _lib.check(_lib.lib().gsv_op_decode_attn(q.data_ptr(), kc.data_ptr(), vc.data_ptr(), kv_len.data_ptr(), active.data_ptr(),
+                                             B, H, smax, code, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.all(out[-1] == 7.0)
+    qf = q.float().view(B, H, 1, HD)
+    for b, n in enumerate(lens):
+        k = kc[b, :, : n + 1].float()
+        v = vc[b, :, : n + 1].float()
+        p = torch.softmax((qf[b] @ k.transpose(1, 2)) / HD ** 0.5, dim=-1)
+        ref = (p @ v).reshape(-1)
+        err = (out[b].float() - ref).abs().max().item()
+        assert err <= tol, (n, err)
