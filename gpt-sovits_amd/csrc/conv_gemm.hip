@@ -174,6 +174,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(ConvArgs a) {
   }
 }
 
+static long long small_tiles_below() {
+  static const long long v = getenv("GSV_CONV_GEMM_SMALL_TILES") ? atoll(getenv("GSV_CONV_GEMM_SMALL_TILES")) : 64;   // A/B switch (0 = off)
+  return v;
+}
+
 template <typename T> static int launch_t(const ConvArgs& a, hipStream_t s) {
   constexpr int G = DT<T>::G;
   GSV_REQUIRE(a.Cin % G == 0, "conv_gemm: Cin=%d must be a multiple of %d", a.Cin, G);
@@ -191,6 +196,11 @@ template <typename T> static int launch_t(const ConvArgs& a, hipStream_t s) {
   } else if (a.Cout <= 64) {
     dim3 grid(cdiv(a.T_virt, 256), cdiv(a.Cout, 64), a.Z);
     hipLaunchKernelGGL((conv_gemm_kernel<T, 2, 2, 1, 4>), grid, dim3(256), 0, s, a);
+  } else if ((long long)cdiv(a.T_virt, 128) * cdiv(a.Cout, 128) * a.Z < small_tiles_below()) {
+    // a handful of 128 x 128 tiles (single-utterance enc_p / flow convs: 200 frames x 384 channels = 6 workgroups, each
+    // a serial chain over taps x Cin): 64 x 64 tiles put four times as many CUs on the same chain length
+    dim3 grid(cdiv(a.T_virt, 64), cdiv(a.Cout, 64), a.Z);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 1, 1, 2, 2>), grid, dim3(256), 0, s, a);
   } else {
     dim3 grid(cdiv(a.T_virt, 128), cdiv(a.Cout, 128), a.Z);
     hipLaunchKernelGGL((conv_gemm_kernel<T, 2, 2, 2, 2>), grid, dim3(256), 0, s, a);
