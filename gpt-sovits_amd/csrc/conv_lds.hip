@@ -725,7 +725,10 @@ template <int CC, int TM, int TN, int WN>
 static int launch_narrow(const ConvArgs& a, int rows_win, hipStream_t s) {
   const int ntiles = cdiv(a.T_virt, 256);
   const size_t lds = ((size_t)rows_win + (size_t)a.taps * 32 * TM) * (CC + 8) * 2;
-  const int per_cu = lds <= 50 * 1024 ? 3 : (lds <= 78 * 1024 ? 2 : 1);
+  // resident workgroups per CU: as many as the LDS footprint allows, capped (GSV_NARROW_PER_CU, default 3).  These stages
+  // are HBM-bound and every workgroup keeps one tile's window + operands in flight, so residency = bytes in flight.
+  static const int cap = getenv("GSV_NARROW_PER_CU") ? std::max(1, atoi(getenv("GSV_NARROW_PER_CU"))) : 3;
+  const int per_cu = std::max(1, std::min(cap, (int)((156 * 1024) / lds)));
   const int grid = std::min(ntiles, 256 * per_cu);
   const bool res = a.res != nullptr, acc = a.accumulate != 0;
 #define GSV_NARROW(R, A)                                                                                                   \
