@@ -172,9 +172,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         # a step is complete when step() returns: rank 0 then holds the int16 audio on the host (the D2H copy inside is
-        # synchronous).  No device-wide synchronize per step: on this ROCm build hipDeviceSynchronize itself intermittently
-        # takes 20-30 ms (runtime housekeeping after ~hundreds of graph launches; GSV_BENCH_TRACE=1 shows it), which is not
-        # synthesis time; the timed region as a whole is still bracketed by synchronize + barrier on both sides.
+        # followed by a stream synchronize), so no device-wide synchronize per step is needed; the timed region as a whole
+        # is bracketed by synchronize + barrier on both sides.  (The 20-30 ms stalls once seen here were the pageable
+        # result copy, see gsv/hostcopy.py; GSV_BENCH_TRACE=1 still splits a step into run + trailing synchronize.)
         ts = time.perf_counter()
         out = step()
         t_run = time.perf_counter() - ts
