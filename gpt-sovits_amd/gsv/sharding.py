@@ -52,7 +52,9 @@ def unpack_segments(buf: torch.Tensor) -> List[dict]:
     for i in range(n):
         ph = a[o:o + lens[i]]
         o += lens[i]
-        out.append({"phones": ph, "bert_features": torch.zeros(1024, lens[i]), "norm_text": "x" * tl[i]})
+        # all-zero BERT features by definition of this wire format: None is the engine's spelling of that (no 1024 x X
+        # zero block is allocated and scanned per segment and step)
+        out.append({"phones": ph, "bert_features": None, "norm_text": "x" * tl[i]})
     return out
 
 

@@ -166,3 +166,22 @@ def test_tts_run_prompt_free_matches_oracle_chain():
     ref = (torch.cat(parts) * 32768).to(torch.int32).to(torch.int16).numpy()
     assert audio.shape == ref.shape
     assert np.abs(audio.astype(np.int32) - ref.astype(np.int32)).max() <= 4
+
+
+def test_none_bert_features_equal_zero_features():
+    """the sharded path's wire format carries no BERT block: `bert_features=None` on a segment must give exactly the
+    audio of the all-zero [1024, X] tensor the reference's non-zh front-end produces (TextPreprocessor.py:216-220)."""
+    tts, *_ = _build()
+    utt = S.make_utterances(3, prompt_phones=6, target_phones=9, prompt_tokens=8, seed=23, ragged=True)
+    refer = S.make_refer_spec(frames=30, seed=5)
+    tts.set_prompt_cache(utt["prompt_semantic"], [refer.to(DEV)], phones=utt["prompt_phones"],
+                         bert_features=torch.zeros(1024, 6), norm_text="xxxxxx")
+    params = {"batch_size": 2, "top_k": 1, "top_p": 1.0, "temperature": 1.0, "repetition_penalty": 1.35, "seed": 3,
+              "split_bucket": True, "fragment_interval": 0.01}
+    outs = []
+    for zero in (True, False):
+        segs = [{"phones": it["phones"], "bert_features": torch.zeros(1024, len(it["phones"])) if zero else None,
+                 "norm_text": it["norm_text"]} for it in utt["items"]]
+        (sr, audio), = list(tts.run(dict(params, segments=segs)))
+        outs.append(audio.copy())
+    assert outs[0].size > 0 and np.array_equal(outs[0], outs[1])
