@@ -117,9 +117,20 @@ class ShardedSynthesizer:
             fbufs = [torch.zeros_like(fl) for _ in range(self.world)]
             dist.gather(pad, bufs, dst=0, group=self.group)
             dist.gather(fl, fbufs, dst=0, group=self.group)
-            arrays = [to_host(b.view(torch.int16)[: int(n.item())]) for b, n in zip(bufs, all_n)]
+            # submission order is restored ON THE DEVICE (one concatenation of fragment views), then a single copy brings
+            # the result to the host: with 8 ranks the host-side concatenate of 70 MB was ~10 ms of rank 0's step
             lens = [f[: len(s)].cpu().tolist() for f, s in zip(fbufs, shares)]
-            return _reorder(arrays, lens, shares, len(segments))
+            views = [b.view(torch.int16) for b in bufs]
+            frags: List[Optional[torch.Tensor]] = [None] * len(segments)
+            for v, ln_r, idxs in zip(views, lens, shares):
+                o = 0
+                for ln, i in zip(ln_r, idxs):
+                    frags[i] = v[o:o + ln]
+                    o += ln
+            keep = [f for f in frags if f is not None]
+            if not keep:
+                return np.zeros(0, dtype=np.int16)
+            return to_host(torch.cat(keep))
         dist.gather(pad, None, dst=0, group=self.group)
         dist.gather(fl, None, dst=0, group=self.group)
         return None
