@@ -11,27 +11,17 @@ from typing import List, Tuple
 
 import torch
 
-# process_ckpt.py:72-80: code -> [symbol version, model version, is_lora]
-head2version = {
-    b"00": ["v1", "v1", False],
-    b"01": ["v2", "v2", False],
-    b"02": ["v2", "v3", False],
-    b"03": ["v2", "v3", True],
-    b"04": ["v2", "v4", True],
-    b"05": ["v2", "v2Pro", False],
-    b"06": ["v2", "v2ProPlus", False],
-}
-# process_ckpt.py:22-27: what the writer stamps
-model_version2byte = {"v3": b"03", "v4": b"04", "v2Pro": b"05", "v2ProPlus": b"06"}
-# process_ckpt.py:81-88: md5 of the first 8192 bytes of the published base models
-hash_pretrained_dict = {
-    "dc3c97e17592963677a4a1681f30c653": ["v2", "v2", False],
-    "43797be674a37c1c83ee81081941ed0f": ["v2", "v3", False],
-    "6642b37f3dbb1f76882b69937c95a5f3": ["v2", "v2", False],
-    "4f26b9476d0c5033e04162c486074374": ["v2", "v4", False],
-    "c7e9fce2223f3db685cdfa1e6368728a": ["v2", "v2Pro", False],
-    "66b313e39455b57ab1b0bc0b239c9d0a": ["v2", "v2ProPlus", False],
-}
+# version codes (process_ckpt.py:63-80): "<2-char code>:<symbol version>:<model version>:<lora 0/1>"
+_CODES = "00:v1:v1:0 01:v2:v2:0 02:v2:v3:0 03:v2:v3:1 04:v2:v4:1 05:v2:v2Pro:0 06:v2:v2ProPlus:0"
+head2version = {c.encode(): [sym, model, lora == "1"] for c, sym, model, lora in (t.split(":") for t in _CODES.split())}
+# what the writer stamps (process_ckpt.py:22-27): only these four model versions are written with a code
+model_version2byte = {m: c for c, (_, m, lora) in head2version.items()
+                      if (m in ("v3", "v4") and lora) or m in ("v2Pro", "v2ProPlus")}
+# md5 of the first 8 KiB of the published base models -> model version (process_ckpt.py:81-88); symbol version is v2, no lora
+_BASE_MD5 = {"v2": ("dc3c97e17592963677a4a1681f30c653", "6642b37f3dbb1f76882b69937c95a5f3"),
+             "v3": ("43797be674a37c1c83ee81081941ed0f",), "v4": ("4f26b9476d0c5033e04162c486074374",),
+             "v2Pro": ("c7e9fce2223f3db685cdfa1e6368728a",), "v2ProPlus": ("66b313e39455b57ab1b0bc0b239c9d0a",)}
+hash_pretrained_dict = {h: ["v2", m, False] for m, hs in _BASE_MD5.items() for h in hs}
 
 
 def get_hash_from_file(sovits_path: str) -> str:
@@ -51,14 +41,12 @@ def get_sovits_version_from_path_fast(sovits_path: str):
         version = f.read(2)
     if version != b"PK":
         return head2version[version]           # unknown code: KeyError, as in the reference
-    size = os.path.getsize(sovits_path)
-    if size < 82978 * 1024:
-        model_version = version = "v1"
-    elif size < 700 * 1024 * 1024:
-        model_version = version = "v2"
-    else:
-        version, model_version = "v2", "v3"
-    return version, model_version, False
+    # plain zip archive (oldest format): v1 files are just under 82978 KiB, v2 a little above, v3 is ~750 MB
+    kib = os.path.getsize(sovits_path) / 1024
+    if kib >= 700 * 1024:
+        return "v2", "v3", False
+    v = "v1" if kib < 82978 else "v2"
+    return v, v, False
 
 
 def load_sovits_new(sovits_path: str) -> dict:

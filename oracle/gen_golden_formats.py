@@ -33,7 +33,10 @@ def payload(version):
 def main():
     import process_ckpt as rp
     cwd = os.getcwd()
-    expect = {"files": {}, "wav_header": {}}
+    expect = {"files": {}, "wav_header": {},
+              "tables": {"head2version": {k.decode(): v for k, v in rp.head2version.items()},
+                         "model_version2byte": {k: v.decode() for k, v in rp.model_version2byte.items()},
+                         "hash_pretrained_dict": rp.hash_pretrained_dict}}
     for version in ("v3", "v4", "v2Pro", "v2ProPlus"):
         path = os.path.join(GOLD, f"fmt_{version}.pth")
         rp.my_save2(payload(version), path, version)

@@ -80,3 +80,10 @@ def test_pack_audio_raw_and_wav():
             wire.pack_audio(BytesIO(), pcm, 32000, mt)
     with pytest.raises(TypeError):
         wire.pack_wav(BytesIO(), pcm.astype(np.float32), 32000)
+
+
+def test_version_tables_equal_the_reference():
+    t = EXPECT["tables"]
+    assert {k.decode(): v for k, v in pc.head2version.items()} == t["head2version"]
+    assert {k: v.decode() for k, v in pc.model_version2byte.items()} == t["model_version2byte"]
+    assert pc.hash_pretrained_dict == t["hash_pretrained_dict"]
