@@ -31,6 +31,10 @@ for p in (ROOT, os.path.join(ROOT, "gpt-sovits_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# the host driver only supports dmabuf IPC: RCCL between ranks needs this (already exported on the pool; kept here so a
+# bare `torchrun bench.py` works too)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
