@@ -19,30 +19,12 @@
 #include <vector>
 
 #include "common.h"
+#include "t2s_sample.h"
+#include "t2s_mega.h"
 
 namespace gsv {
 
 typedef float f4v __attribute__((ext_vector_type(4)));
-
-// ---------------------------------------------------------------------------------------
-// device-side parameter block shared by the step kernels (lives in HBM so that the captured
-// graph does not bake sampling parameters)
-// ---------------------------------------------------------------------------------------
-struct StepParams {
-  int top_k;
-  float top_p;
-  float temperature;
-  float rep_penalty;
-  int early_stop_num;
-  int eos_mask_steps;
-  int max_steps;
-  int noise_rows;          // 0: counter RNG, 1: shared noise, B: per-row noise
-  unsigned long long seed;
-  const float* noise;      // [max_steps][noise_rows][V] or null
-  int* out_tokens;         // [B][max_steps]
-  int* out_len;            // [B]
-  int P;                   // prompt length (position offset of generated tokens)
-};
 
 // =======================================================================================
 // kernels
@@ -893,145 +875,6 @@ __global__ __launch_bounds__(256) void dec_qkv_attn_kernel(QkvAttnArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// Sampling (H5): one wave per row, the whole row in registers (NPL values per lane), all
-// reductions are wavefront shuffles.  Semantics follow reference AR/models/utils.py:147-199:
-// repetition penalty (in place, so the EOS argmax test of t2s_model.py:721 sees penalised
-// logits) -> top-p on the un-tempered distribution -> /temperature -> top-k (ties kept) ->
-// softmax -> argmax(p / Exp(1)).  No sort: tokens are extracted in descending order only as
-// far as top-k / top-p need.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
-
-struct ArgMax { float v; int i; };
-__device__ __forceinline__ ArgMax wave_argmax(float v, int i) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float ov = __shfl_xor(v, o, 64);
-    int oi = __shfl_xor(i, o, 64);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-  }
-  return {v, i};
-}
-
-template <int NPL>
-__device__ void sample_row(const float* __restrict__ lg_row, int V, int Veff, const int* __restrict__ prev, int prev_len,
-                           int top_k, float top_p, float temperature, float rp, const float* __restrict__ noise_row,
-                           unsigned long long seed, int row, int step, unsigned char* seen /* LDS [V] */,
-                           int* out_sample, int* out_argmax) {
-  const int lane = threadIdx.x & 63;
-  float x[NPL];
-  // token v = lane + 64*i  (coalesced loads, low index first inside a lane)
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int v = lane + 64 * i;
-    x[i] = (v < Veff) ? lg_row[v] : -INFINITY;
-  }
-  if (rp != 1.0f) {
-    for (int v = lane; v < V; v += 64) seen[v] = 0;
-    __syncthreads();
-    for (int t = lane; t < prev_len; t += 64) {
-      int tok = prev[t];
-      if (tok >= 0 && tok < V) seen[tok] = 1;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      const int v = lane + 64 * i;
-      if (v < Veff && seen[v]) x[i] = (x[i] < 0.f) ? x[i] * rp : x[i] / rp;
-    }
-  }
-  // argmax of the penalised logits (first index on ties)
-  float bv = -INFINITY; int bi = 0x7fffffff;
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int v = lane + 64 * i;
-    if (v < Veff && (x[i] > bv)) { bv = x[i]; bi = v; }
-  }
-  ArgMax am = wave_argmax(bv, bi);
-  *out_argmax = am.i;
-  const float max0 = am.v;
-
-  const bool use_p = top_p < 1.0f;
-  const bool use_k = top_k > 0 && top_k < Veff;
-  unsigned int keep = 0;  // bit i: x[i] survives the filters
-  if (!use_p && !use_k) {
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) if (lane + 64 * i < Veff) keep |= 1u << i;
-  } else {
-    float S = 1.f;
-    if (use_p) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) if (lane + 64 * i < Veff) s += expf(x[i] - max0);
-      S = wave_sum(s);
-    }
-    unsigned int taken = 0;
-    float cum = 0.f, pivot = 0.f;
-    bool have_pivot = false;
-    for (int r = 0; r < Veff; ++r) {
-      float cv = -INFINITY; int ci = 0x7fffffff; int cslot = -1;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) {
-        const int v = lane + 64 * i;
-        if (v < Veff && !((taken >> i) & 1u) && x[i] > cv) { cv = x[i]; ci = v; cslot = i; }
-      }
-      ArgMax e = wave_argmax(cv, ci);
-      if (e.i == 0x7fffffff || e.v == -INFINITY) break;  // nothing finite left
-      bool kept = true;
-      if (use_p) {
-        cum += expf(e.v - max0) / S;
-        if (r > 0 && cum > top_p) kept = false;
-      }
-      if (!kept) break;                  // top-p removes this and everything after it
-      if (use_k) {
-        if (r == top_k - 1) { pivot = e.v; have_pivot = true; }
-        else if (r >= top_k && !(have_pivot && e.v == pivot)) break;  // past the k-th value and not a tie
-      }
-      if (ci == e.i && cslot >= 0) {
-        // the owning lane marks the token as taken and kept
-#pragma unroll
-        for (int i = 0; i < NPL; ++i) if (i == cslot) { taken |= 1u << i; keep |= 1u << i; }
-      }
-    }
-  }
-  // softmax over the kept set at temperature T, then the exponential race
-  const float tdiv = fmaxf(temperature, 1e-5f);
-  float lm = -INFINITY;
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) if ((keep >> i) & 1u) lm = fmaxf(lm, x[i] / tdiv);
-  lm = wave_max(lm);
-  float z = 0.f;
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) if ((keep >> i) & 1u) z += expf(x[i] / tdiv - lm);
-  z = wave_sum(z);
-  float sv = -INFINITY; int si = 0x7fffffff;
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int v = lane + 64 * i;
-    // filtered-out tokens have p = 0 and score 0 / q = 0: they can only win when no kept token has a
-    // positive score, which cannot happen (rank 0 is always kept), so their Exp(1) draw is never needed
-    if (v >= Veff || !((keep >> i) & 1u)) continue;
-    float p = expf(x[i] / tdiv - lm) / z;
-    float qn;
-    if (noise_row) qn = noise_row[v];
-    else {
-      unsigned long long hsh = splitmix64(seed ^ splitmix64(((unsigned long long)row << 40) ^ ((unsigned long long)step << 20) ^ (unsigned long long)v));
-      float u = (float)(hsh >> 40) * (1.0f / 16777216.0f);
-      qn = fmaxf(-log1pf(-u), 1e-20f);
-    }
-    float sc = p / qn;
-    if (sc > sv || (sc == sv && v < si)) { sv = sc; si = v; }
-  }
-  ArgMax sm = wave_argmax(sv, si);
-  *out_sample = sm.i;
-}
-
 // step tail: sample every row, update row state, emit the next step's input embedding
 // (t2s_model.py:714-769).  grid = B, block = 64.
 template <int NPL>
@@ -1134,6 +977,13 @@ struct gsv_t2s {
   void* pf_bert_t = nullptr;
   // current batch
   int B = 0, P = 0;
+  int max_kv0 = 0;          // longest row's cached positions after prefill (host copy: bounds the decode budget)
+  // persistent decode engine (t2s_mega.hip): fp16, v1/v2 shape, B <= 32; the launch-per-phase step stays as the
+  // fp32 / other-shape path and behind GSV_T2S_NO_MEGA=1 for A/B
+  MegaState mega;
+  hipEvent_t mega_ev[2] = {nullptr, nullptr};
+  float last_decode_ms = 0.f; int last_decode_steps = 0; int last_decode_mode = 0;
+  bool mega_on = true;      // gsv_t2s_set_mega (A/B inside one process); GSV_T2S_NO_MEGA=1 never builds the engine
   std::map<int, hipGraphExec_t> graphs;
   std::vector<void*> allocs;
 };
@@ -1258,6 +1108,8 @@ void gsv_t2s_destroy(gsv_t2s_t* h) {
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.second);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  if (h->mega.h_err) (void)hipHostFree(h->mega.h_err);
+  for (auto& e : h->mega_ev) if (e) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -1286,6 +1138,7 @@ int gsv_t2s_finalize(gsv_t2s_t* h) {
     auto it = h->staged.find("pe");
     GSV_REQUIRE(it != h->staged.end() && it->second.size() % d == 0, "t2s: missing sinusoid table 'pe' [n_pos][dim]");
     h->pe_rows = (int)(it->second.size() / d);
+    GSV_REQUIRE(h->max_seq <= h->pe_rows, "t2s: max_seq %d exceeds the position table (%d rows)", h->max_seq, h->pe_rows);
     GSV_RC(upload_f32(h, it->second, &h->pe));
   }
   GSV_GET("ar_predict_layer.weight", V * d); GSV_RC(upload_t(h, *t, &h->pred_w));
@@ -1306,6 +1159,36 @@ int gsv_t2s_finalize(gsv_t2s_t* h) {
     GSV_GET(p + "norm2.bias", d); GSV_RC(upload_f32(h, *t, &L.n2b));
   }
 #undef GSV_GET
+  if (h->dtype == GSV_F16 && mega_shape_ok(c.dim, c.n_head, c.ffn_dim, c.vocab) && !getenv("GSV_T2S_NO_MEGA")) {
+    // second copy of the decoder weights in the persistent engine's load order (every wave load = 1 KiB contiguous)
+    MegaState& m = h->mega;
+    const size_t lh = mega_layer_pack_halfs(), gh = mega_logits_pack_halfs();
+    GSV_RC(dev_alloc(h, &m.wpack, (size_t)c.n_layer * lh * 2));
+    GSV_RC(dev_alloc(h, &m.lpack, gh * 2));
+    std::vector<_Float16> tmp(std::max(lh, gh));
+    for (int i = 0; i < c.n_layer; ++i) {
+      std::string p = "h.layers." + std::to_string(i) + ".";
+      mega_pack_layer(h->staged[p + "self_attn.in_proj_weight"].data(), h->staged[p + "self_attn.out_proj.weight"].data(),
+                      h->staged[p + "linear1.weight"].data(), h->staged[p + "linear2.weight"].data(), tmp.data());
+      GSV_HIP(hipMemcpy((char*)m.wpack + (size_t)i * lh * 2, tmp.data(), lh * 2, hipMemcpyHostToDevice));
+    }
+    mega_pack_logits(h->staged["ar_predict_layer.weight"].data(), c.vocab, tmp.data());
+    GSV_HIP(hipMemcpy(m.lpack, tmp.data(), gh * 2, hipMemcpyHostToDevice));
+    std::vector<MegaLayerP> lp(c.n_layer);
+    for (int i = 0; i < c.n_layer; ++i) {
+      const LayerW& L = h->layers[i];
+      lp[i] = MegaLayerP{L.qkv_b, L.out_b, L.b1, L.b2, L.n1w, L.n1b, L.n2w, L.n2b};
+    }
+    GSV_RC(dev_alloc(h, (void**)&m.lp, lp.size() * sizeof(MegaLayerP)));
+    GSV_HIP(hipMemcpy(m.lp, lp.data(), lp.size() * sizeof(MegaLayerP), hipMemcpyHostToDevice));
+    m.hop_bytes = mega_hop_bytes();
+    GSV_RC(dev_alloc(h, (void**)&m.hop, m.hop_bytes));
+    GSV_RC(dev_alloc(h, (void**)&m.err, 64));
+    GSV_HIP(hipHostMalloc((void**)&m.h_err, 64));
+    GSV_HIP(hipEventCreate(&h->mega_ev[0]));
+    GSV_HIP(hipEventCreate(&h->mega_ev[1]));
+    m.ready = true;
+  }
   h->staged.clear();
   const size_t B = h->max_batch, es = esz(h);
   h->kv_layer_stride = B * d * (size_t)h->max_seq;
@@ -1502,7 +1385,7 @@ int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_le
     const size_t need_vt = (size_t)B * H * 32 * ((maxS + 31) / 32 * 32) * 2;
     if (need_vt > h->pf_vt_cap) { GSV_RC(dev_alloc(h, &h->pf_vt, need_vt + need_vt / 4)); h->pf_vt_cap = need_vt + need_vt / 4; }
   }
-  h->B = B; h->P = P;
+  h->B = B; h->P = P; h->max_kv0 = maxS;
   GSV_HIP(hipMemcpyAsync(h->d_x_len, phone_lens, B * 4, hipMemcpyHostToDevice, s));
   GSV_HIP(hipMemcpyAsync(h->d_row_off, row_off.data(), B * 4, hipMemcpyHostToDevice, s));
   GSV_HIP(hipMemcpyAsync(h->d_ph_off, ph_off.data(), B * 4, hipMemcpyHostToDevice, s));
@@ -1596,14 +1479,61 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
   p.P = h->P;
   GSV_HIP(hipMemcpyAsync(h->d_sp, &p, sizeof(p), hipMemcpyHostToDevice, s));
   GSV_HIP(hipStreamSynchronize(s));
-  // budget: every step appends one position
-  int kvmin_room = h->max_seq;
+  // budget: step 0 samples from the prefill's last position, every later step appends one K/V position, so the
+  // longest row ends at max_kv0 + budget - 1 cached positions; the sampling tail reads pe[P + step] and writes
+  // token history [P + step].  A request that does not fit is refused here: the kernels clamp out-of-range
+  // appends, which would otherwise yield silently wrong tokens with rc 0.
   int budget = sp->max_steps;
   if (sp->early_stop_num >= 0 && sp->early_stop_num + 1 < budget) budget = sp->early_stop_num + 1;
-  (void)kvmin_room;
+  GSV_REQUIRE(h->max_kv0 + budget <= h->max_seq,
+              "t2s_decode: %d cached positions + %d steps exceed the K/V arena (max_seq %d); lower max_steps / early_stop_num "
+              "or create the engine with a larger max_seq", h->max_kv0, budget, h->max_seq);
+  GSV_REQUIRE(h->P + budget <= h->pe_rows, "t2s_decode: prompt %d + %d steps exceed the position table (%d rows)", h->P, budget,
+              h->pe_rows);
   // step 0: logits of the last prefill position, sample, emit first embedding
   GSV_RC(launch_tail(h, s));
   int steps = 1;
+  h->last_decode_mode = 0; h->last_decode_ms = 0.f; h->last_decode_steps = 0;
+  if (h->mega.ready && h->mega_on && h->B <= MEGA_MAX_B && budget > 1) {
+    MegaState& m = h->mega;
+    if (m.census < 0) {
+      // once per handle: are the engine's 256 workgroups co-resident on this device?  If not, a hand-off could wait
+      // for a workgroup that never starts: the launch-per-phase step is used instead (gsv_t2s_decode_info reports it)
+      const int rc = mega_census(s, m.err, m.h_err);
+      if (rc < 0) return rc;
+      m.census = rc;
+    }
+    if (m.census == 1) {
+      static const bool map_local = getenv("GSV_MEGA_GROUP_XCD") != nullptr;
+      GSV_HIP(hipMemsetAsync(m.hop, 0, m.hop_bytes, s));      // tags restart at 1 every call
+      GSV_HIP(hipMemsetAsync(m.err, 0, 64, s));
+      MegaArgs a;
+      memset(&a, 0, sizeof(a));
+      a.wpack = (const h8*)m.wpack; a.lpack = (const h8*)m.lpack; a.lp = m.lp;
+      a.kv = (_Float16*)h->kv; a.kv_layer_stride = h->kv_layer_stride; a.smax = h->max_seq;
+      a.kv_len = h->d_kv_len; a.active = h->d_active; a.step_ctr = h->d_step; a.n_active = h->d_n_active;
+      a.ytok = h->d_ytok; a.ycap = h->ycap; a.sp = h->d_sp; a.e_audio = h->e_audio; a.pe = h->pe; a.alpha_a = h->alpha_a;
+      a.ybuf = h->ybuf; a.logits_out = h->logits; a.hop = m.hop; a.err = m.err; a.B = h->B; a.L = h->cfg.n_layer; a.V = h->cfg.vocab;
+      a.nsteps = budget - 1; a.map_shared = map_local ? 0 : 1;
+      GSV_HIP(hipEventRecord(h->mega_ev[0], s));
+      GSV_RC(launch_t2s_mega(a, s));
+      GSV_HIP(hipEventRecord(h->mega_ev[1], s));
+      GSV_HIP(hipMemcpyAsync(m.h_err, m.err, 16, hipMemcpyDeviceToHost, s));
+      GSV_HIP(hipMemcpyAsync(h->h_pinned, h->d_step, 4, hipMemcpyDeviceToHost, s));
+      GSV_HIP(hipStreamSynchronize(s));
+      if (m.h_err[0] != 0u) {
+        set_error("t2s_decode: persistent engine hand-off timed out (epoch %u, workgroup %u, hop code %u); "
+                  "set GSV_T2S_NO_MEGA=1 to use the launch-per-phase step", m.h_err[1], m.h_err[2], m.h_err[3]);
+        return GSV_ERR_STATE;
+      }
+      (void)hipEventElapsedTime(&h->last_decode_ms, h->mega_ev[0], h->mega_ev[1]);
+      // every row ends by the budget's last step (early == step >= max_steps - 1); row 0's step counter tells how
+      // far the longest-running group got only for its own group, so report the budget like the launch loop does
+      h->last_decode_mode = 1; h->last_decode_steps = budget - 1;
+      if (steps_run) *steps_run = budget;
+      return GSV_OK;
+    }
+  }
   // steps >= 1 : captured once per batch size, replayed
   hipGraphExec_t exec = nullptr;
   auto it = h->graphs.find(h->B);
@@ -1633,6 +1563,20 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
   }
   GSV_HIP(hipStreamSynchronize(s));
   if (steps_run) *steps_run = steps;
+  return GSV_OK;
+}
+
+int gsv_t2s_set_mega(gsv_t2s_t* h, int on) {
+  GSV_REQUIRE(h, "t2s_set_mega: null handle");
+  h->mega_on = on != 0;
+  return GSV_OK;
+}
+
+int gsv_t2s_decode_info(gsv_t2s_t* h, int* mode, float* device_ms, int* steps) {
+  GSV_REQUIRE(h && h->finalized, "t2s_decode_info: handle not finalized");
+  if (mode) *mode = h->last_decode_mode;
+  if (device_ms) *device_ms = h->last_decode_ms;
+  if (steps) *steps = h->last_decode_steps;
   return GSV_OK;
 }
 

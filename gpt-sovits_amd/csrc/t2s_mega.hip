@@ -1,0 +1,811 @@
+// Persistent AR decode engine for gfx950: every step of a decode call (reference AR/models/t2s_model.py:694-769: the
+// `for idx in range(1500)` loop of infer_panel_batch_infer, 24 x T2SBlock.decode_next_token :176-221, ar_predict_layer,
+// sample :AR/models/utils.py:140-199, EOS / early-stop bookkeeping) runs inside ONE kernel launch.
+//
+// Why: as five launches per layer the step is a chain of 122 dependent kernels of 4.6-7 us that each move 0.5-18 MB
+// (round 1: 0.67 ms per step at B = 32, 11 % of the HBM roofline); nothing in it is bandwidth-bound, every kernel spends
+// its life ramping up and waiting for its first bytes.  Here the chain's hand-offs stay on the chip and the weights are
+// already in registers when a hand-off completes.
+//
+// Decomposition (measured first with tools/mega_probe.hip, profiles/r02_mega_probe.txt):
+//   * rows are independent, so the batch is split into 8 GROUPS of R = ceil(B/8) rows (row b -> group b % 8); a group
+//     is served by 32 workgroups (one per CU, 512 threads) that never talk to another group: no grid-wide barrier.
+//   * inside a group the layer is tensor-parallel over the 32 members: member j = (head j/2, row parity j%2) computes
+//     q,k,v of its head for its rows, appends K/V, attends (all local), then the out-projection, FFN1 and FFN2 are
+//     split over output columns (16 / 64 / 16 columns per member).  Between phases the members all-gather the small
+//     activation vector (R x 512 fp32, R x 512 fp16, R x 2048 fp16): 4 hops per layer.
+//   * a hop = 8-byte {tag = epoch, value} granules written with sc1 (write-through) stores and swept with sc1 loads
+//     until every tag matches (MI355X_MICROARCH.md, visibility: R2 "the data is the flag"; no fence, no flag, placement
+//     independent).  Every spin is bounded; a timeout sets an error word and every workgroup leaves.
+//   * waves 0-3 of a workgroup ("comm") sweep hops into LDS and do the LayerNorms; waves 4-7 ("compute") hold the
+//     member's weight slices in REGISTERS, prefetched one phase ahead with perfectly coalesced 1 KiB wave loads from a
+//     copy of the weights packed in exactly that order, run the MFMAs (K split over the 4 waves in the same 128-wide
+//     chunks and summation order as dec_gemm_kernel), reduce through LDS and publish.
+//   * K/V of the member's (head, rows) is prefetched into LDS by LDS-DMA (non-temporal) one layer ahead.
+//   * blockIdx -> (group, member): the 8 workgroups that read the SAME weight slice (one per group) are placed on the
+//     same XCD (blockIdx % 8 under the observed round-robin placement), so a slice is filled into that L2 once and hit
+//     seven times; the hops are sc1 and do not care.  Correctness never depends on the placement.
+//   * logits are split over the members too; row r of a group is sampled by member r (one wave, sample_core of
+//     t2s_sample.h), which also emits the next input embedding: the step's tail is two more hops.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "t2s_mega.h"
+
+namespace gsv {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef unsigned long long u64;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+// Workgroup barrier WITHOUT __syncthreads()'s release fence: that fence is an s_waitcnt vmcnt(0), which would drain the
+// weight prefetch (issued one phase ahead on purpose) at every barrier -- tools/mega_probe.hip measured hops and weight
+// stream adding up instead of overlapping with it.  LDS traffic of this wave is complete (lgkmcnt(0)) before the barrier;
+// the "memory" clobber keeps the compiler from moving memory operations across it.
+#define MG_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+namespace {
+
+constexpr int MG_GROUPS = 8, MG_MEMBERS = 32, MG_NWG = MG_GROUPS * MG_MEMBERS, MG_THREADS = 512;
+constexpr int RMAX = 4;                       // rows per group (B <= 32)
+constexpr int D = 512, NH = 16, HD = 32, FF = 2048;
+constexpr int XS_LD = 528, HS_LD = 2064;      // LDS row strides in halfs (rows 32 B apart mod 256 B: conflict-free b128 reads)
+constexpr int KV_CAP = 320;                   // cached positions per own row held in the LDS image (rest: global loads)
+constexpr int VPAD = 1088;                    // logits row stride in the hop buffer (17 x 64)
+constexpr unsigned SPIN_MAX = 1u << 18;
+
+// packed weight geometry (KiB-instructions per compute wave)
+constexpr int WI_P1 = 24, WI_P2 = 4, WI_P3 = 16, WI_P4 = 16, WI_LG = 12;
+constexpr size_t P1_HALFS = (size_t)NH * 4 * WI_P1 * 512;                       // per layer, by head
+constexpr size_t PM_HALFS = (size_t)MG_MEMBERS * 4 * (WI_P2 + WI_P3 + WI_P4) * 512;  // per layer, by member
+constexpr size_t LAYER_HALFS = P1_HALFS + PM_HALFS;
+constexpr size_t LOGIT_HALFS = (size_t)MG_MEMBERS * 4 * WI_LG * 512;
+
+// hop buffers of one group, in granules
+constexpr int HOP_A = 0;                            // [RMAX][512] fp32 y  + RMAX state granules
+constexpr int HOP_ST = RMAX * 512;
+constexpr int HOP_B = HOP_ST + 64;                  // [RMAX][256] half pairs (attention output)
+constexpr int HOP_C = HOP_B + RMAX * 256;           // [RMAX][512] fp32 y1
+constexpr int HOP_D = HOP_C + RMAX * 512;           // [RMAX][1024] half pairs (FFN hidden)
+constexpr int HOP_E = HOP_D + RMAX * 1024;          // [RMAX][VPAD] fp32 logits
+constexpr int HOP_GROUP = HOP_E + RMAX * VPAD;
+
+// LDS carve (bytes); everything dynamic so the base stays 16-byte aligned
+constexpr int L_Y = 0;                                        // fp32 [RMAX][512]   (unused rows stay zero)
+constexpr int L_XRES = L_Y + RMAX * 512 * 4;                  // fp32 [RMAX][512]   LayerNorm output (residual operand)
+constexpr int L_XS = L_XRES + RMAX * 512 * 4;                 // half [RMAX][XS_LD] LayerNorm output (MFMA operand)
+constexpr int L_AT = L_XS + RMAX * XS_LD * 2;                 // half [RMAX][XS_LD] attention output of all heads
+constexpr int L_HS = L_AT + RMAX * XS_LD * 2;                 // half [RMAX][HS_LD] FFN hidden
+constexpr int L_RED = L_HS + RMAX * HS_LD * 2;                // f4 [24][64] split-K partials
+constexpr int L_QKV = L_RED + 24 * 64 * 16;                   // half [2][3][32] q,k,v of the own rows
+constexpr int L_ATT = L_QKV + 2 * 3 * 32 * 2;                 // float [4] m + [4][36] acc,l
+constexpr int L_ST = L_ATT + 16 + 4 * 36 * 4;                 // int: active[RMAX], kvlen[RMAX], step[RMAX], abort, any_active
+constexpr int L_SEEN = L_ST + 64;                             // bytes [VPAD]
+constexpr int L_KV = (L_SEEN + VPAD + 63) & ~63;              // [2 rows][K|V][KV_CAP][64 B]
+constexpr int L_TOTAL = L_KV + 2 * 2 * KV_CAP * 64;
+static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
+static_assert(L_XS % 16 == 0 && L_AT % 16 == 0 && L_HS % 16 == 0 && L_RED % 16 == 0 && L_QKV % 16 == 0 && L_KV % 16 == 0, "LDS alignment");
+
+__device__ __forceinline__ void gstore(gu64* p, unsigned tag, unsigned val) {
+  __hip_atomic_store(p, ((u64)tag << 32) | val, RLX_AGENT);           // global_store_dwordx2 ... sc1 (one untorn granule)
+}
+__device__ __forceinline__ u64 gload(gu64* p) { return __hip_atomic_load(p, RLX_AGENT); }   // global_load_dwordx2 ... sc1
+
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {
+  const h2 v = (h2){(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// LDS-DMA of one KiB (16 B per lane, lane i -> lds_dst + 16 i), non-temporal; invisible to the compiler's vmcnt
+// bookkeeping (cdna_hip_programming.md 5.7): the consumer waits with asm vmcnt(0) + a workgroup barrier
+__device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+struct Ctx {
+  unsigned char* smem;
+  int lane, wave, cw, tid_c;
+  bool comm;
+  int group, member, head, half, R;
+  gu64* hop;
+  gu32* err;
+};
+
+__device__ __forceinline__ int* st_active(const Ctx& c) { return (int*)(c.smem + L_ST); }
+__device__ __forceinline__ int* st_kvlen(const Ctx& c) { return (int*)(c.smem + L_ST) + RMAX; }
+__device__ __forceinline__ int* st_step(const Ctx& c) { return (int*)(c.smem + L_ST) + 2 * RMAX; }
+__device__ __forceinline__ volatile int* st_abort(const Ctx& c) { return (volatile int*)(c.smem + L_ST) + 3 * RMAX; }
+__device__ __forceinline__ volatile int* st_any(const Ctx& c) { return (volatile int*)(c.smem + L_ST) + 3 * RMAX + 1; }
+
+__device__ __noinline__ void mega_fail(const Ctx& c, unsigned epoch, unsigned code) {
+  *st_abort(c) = 1;
+  if (c.lane == 0) {
+    __hip_atomic_store(c.err + 1, epoch, RLX_AGENT);
+    __hip_atomic_store(c.err + 2, (unsigned)blockIdx.x, RLX_AGENT);
+    __hip_atomic_store(c.err + 3, code, RLX_AGENT);
+    __hip_atomic_store(c.err, 1u, RLX_AGENT);
+  }
+}
+
+// one wave re-reads its N granules per lane (granule k*64 + lane of `g`) until every tag equals `epoch`
+template <int N>
+__device__ __forceinline__ bool sweep(const Ctx& c, gu64* g, int nvalid, unsigned epoch, unsigned (&v)[N], unsigned code) {
+  for (unsigned spins = 0;; ++spins) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int i = k * 64 + c.lane;
+      if (i < nvalid) {
+        const u64 x = gload(g + i);
+        v[k] = (unsigned)x;
+        ok &= (unsigned)(x >> 32) == epoch;
+      } else {
+        v[k] = 0u;
+      }
+    }
+    if (__all(ok)) return true;
+    if (spins > SPIN_MAX || *st_abort(c) || (spins & 1023u) == 1023u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
+      mega_fail(c, epoch, code);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// LayerNorm of one row held as 8 values per lane (element k*64 + lane); gamma == null: identity (layer 0's embedding)
+__device__ __forceinline__ void ln_row(const Ctx& c, int row, const unsigned (&v)[8], const float* gm, const float* bt) {
+  float x[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = __uint_as_float(v[k]);
+  if (gm) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += x[k];
+    const float mean = wave_sum(s) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float dl = x[k] - mean; q += dl * dl; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = (x[k] - mean) * rstd * gm[k] + bt[k];
+  }
+  float* xr = (float*)(c.smem + L_XRES) + row * D;
+  _Float16* xs = (_Float16*)(c.smem + L_XS) + row * XS_LD;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    xr[k * 64 + c.lane] = x[k];
+    xs[k * 64 + c.lane] = (_Float16)x[k];
+  }
+}
+
+// compute waves: NT tiles x 4 k-steps of this wave's 128-wide K chunk `kc` against the activation image `act`
+// (half [RMAX][ld]); partial tiles go to red[(slot0 + t)][lane]
+template <int NT>
+__device__ __forceinline__ void gemm_chunk(const Ctx& c, const h8 (&w)[NT * 4], const _Float16* act, int ld, int kc, int slot0) {
+  const int rowl = c.lane & 15, kg = c.lane >> 4;
+  const _Float16* bp = act + (rowl & (RMAX - 1)) * ld + kc * 128 + 8 * kg;
+  h8 b[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) b[ks] = *(const h8*)(bp + 32 * ks);
+  f4* red = (f4*)(c.smem + L_RED);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t * 4 + ks], b[ks], acc, 0, 0, 0);
+    red[(slot0 + t) * 64 + c.lane] = acc;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wload(h8 (&dst)[N], const h8* src) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) dst[i] = __builtin_nontemporal_load(src + (size_t)i * 64);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The two roles are separate functions: a weight array defined under `if (!comm)` inside one body would have to keep
+// its old value alive around the whole loop for the other role's lanes, i.e. all 240 weight registers live everywhere.
+// Both roles execute the same sequence of workgroup barriers and take the same (LDS-uniform) exit decisions.
+// ---------------------------------------------------------------------------------------------------------------
+// Make the role's indices opaque to the optimiser at the start of every phase.  Without this, loop-invariant code motion
+// hoists every per-lane address (weight, bias, hop, LDS pointers of all phases) out of the step and layer loops and keeps
+// ~100 of them alive across the whole body: VGPR / SGPR spills in the critical path.  Recomputing an address is 2-3 ALU ops.
+__device__ __forceinline__ void relaunder(Ctx& q) {
+  int cw = __builtin_amdgcn_readfirstlane(q.cw), member = __builtin_amdgcn_readfirstlane(q.member),
+      group = __builtin_amdgcn_readfirstlane(q.group);
+  asm volatile("" : "+v"(q.lane), "+s"(cw), "+s"(member), "+s"(group));
+  q.cw = cw; q.member = member; q.group = group; q.head = member >> 1; q.half = member & 1;
+  q.tid_c = q.cw * 64 + q.lane;
+}
+
+__device__ __forceinline__ bool group_done(const Ctx& c) {
+  int any = 0;
+  for (int r = 0; r < c.R; ++r) any |= st_active(c)[r];
+  return !any;
+}
+
+__device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, const StepParams& sp) {
+  Ctx q = c0;
+  unsigned char* smem = c0.smem;
+  const int R = c0.R;
+  const int V = a.V, EOS = a.V - 1;
+  const bool sampler = c0.member < R && c0.cw == 0;      // wave 0 of member r samples local row r
+  const int EPS = 4 * a.L + 2;                       // hops per step
+  unsigned char* seen = smem + L_SEEN;
+  for (int s = 0; s < a.nsteps; ++s) {
+    const unsigned ep0 = (unsigned)s * (unsigned)EPS;  // epoch of hop i of this step = ep0 + i + 1
+    for (int l = 0; l < a.L; ++l) {
+      const MegaLayerP lp = a.lp[l];
+      relaunder(q);
+      // ---- hop A: y of the previous layer (or the step's input embedding) -> LayerNorm -> XS / XRES
+      {
+        const unsigned ep = ep0 + 4 * l + 1;
+        if (q.cw < R) {
+          unsigned v[8];
+          float gm[8], bt[8];
+          const float* gp = l > 0 ? a.lp[l - 1].n2w : nullptr;
+          const float* bp = l > 0 ? a.lp[l - 1].n2b : nullptr;
+          if (gp) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { gm[k] = gp[k * 64 + q.lane]; bt[k] = bp[k * 64 + q.lane]; }
+          }
+          bool ok = true;
+          if (s == 0 && l == 0) {
+            const float* yb = a.ybuf + (size_t)(q.group + MG_GROUPS * q.cw) * D;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = __float_as_uint(yb[k * 64 + q.lane]);
+          } else {
+            ok = sweep<8>(q, q.hop + HOP_A + q.cw * 512, 512, ep, v, 1u);
+          }
+          if (ok) ln_row(q, q.cw, v, gp ? gm : nullptr, bt);
+        }
+        if (l == 0 && s > 0 && q.cw == 0) {
+          // row state published by the samplers with the embedding: {active} per row
+          unsigned sv[1];
+          if (sweep<1>(q, q.hop + HOP_ST, R, ep, sv, 2u) && q.lane < R) {
+            const int was = st_active(q)[q.lane], now = (int)(sv[0] & 1u);
+            if (was) { st_step(q)[q.lane] += 1; if (now) st_kvlen(q)[q.lane] += 1; }
+            st_active(q)[q.lane] = now;
+          }
+        }
+      }
+      MG_BAR();                                                          // B1
+      if (*st_abort(q)) return;
+      if (l == 0 && s > 0 && group_done(q)) return;                      // every row of the group has finished
+      MG_BAR();                                                          // B2
+      MG_BAR();                                                          // B3
+      MG_BAR();                                                          // B4
+      relaunder(q);
+      // ---- hop B: attention output of all heads -> AT
+      if (q.cw < R) {
+        unsigned v[4];
+        if (sweep<4>(q, q.hop + HOP_B + q.cw * 256, 256, ep0 + 4 * l + 2, v, 3u)) {
+          unsigned* at = (unsigned*)(smem + L_AT) + q.cw * (XS_LD / 2);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) at[k * 64 + q.lane] = v[k];
+        }
+      }
+      MG_BAR();                                                          // B1
+      if (*st_abort(q)) return;
+      MG_BAR();                                                          // B2
+      relaunder(q);
+      // ---- hop C: y1 -> LayerNorm1 -> XS / XRES
+      if (q.cw < R) {
+        unsigned v[8];
+        float gm[8], bt[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { gm[k] = lp.n1w[k * 64 + q.lane]; bt[k] = lp.n1b[k * 64 + q.lane]; }
+        if (sweep<8>(q, q.hop + HOP_C + q.cw * 512, 512, ep0 + 4 * l + 3, v, 4u)) ln_row(q, q.cw, v, gm, bt);
+      }
+      MG_BAR();                                                          // B1
+      if (*st_abort(q)) return;
+      MG_BAR();                                                          // B2
+      relaunder(q);
+      // ---- hop D: h -> HS
+      if (q.cw < R) {
+        unsigned v[16];
+        if (sweep<16>(q, q.hop + HOP_D + q.cw * 1024, 1024, ep0 + 4 * l + 4, v, 5u)) {
+          unsigned* hs = (unsigned*)(smem + L_HS) + q.cw * (HS_LD / 2);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) hs[k * 64 + q.lane] = v[k];
+        }
+      }
+      MG_BAR();                                                          // B1
+      if (*st_abort(q)) return;
+      MG_BAR();                                                          // B2
+    }
+    relaunder(q);
+    // ---- tail: hop A' -> LayerNorm2 of the last layer -> XS; then the samplers
+    const MegaLayerP lpl = a.lp[a.L - 1];
+    const unsigned epA = ep0 + 4 * a.L + 1, epE = ep0 + 4 * a.L + 2;
+    if (q.cw < R) {
+      unsigned v[8];
+      float gm[8], bt[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { gm[k] = lpl.n2w[k * 64 + q.lane]; bt[k] = lpl.n2b[k * 64 + q.lane]; }
+      if (sweep<8>(q, q.hop + HOP_A + q.cw * 512, 512, epA, v, 6u)) ln_row(q, q.cw, v, gm, bt);
+    }
+    MG_BAR();                                                            // B1
+    if (*st_abort(q)) return;
+    MG_BAR();                                                            // B2
+    // ---- sampling of local row `member` (reference utils.py:140-199, t2s_model.py:706-769)
+    if (sampler) {
+      const int r = q.member, b = q.group + MG_GROUPS * r;
+      const unsigned epN = ep0 + (unsigned)EPS + 1;                      // hop A of the next step's layer 0
+      const int was_active = st_active(q)[r];
+      int now_active = 0;
+      float x0[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x0[k] = 0.f;
+      bool ok = true;
+      if (was_active) {
+        const int step = st_step(q)[r];
+        unsigned lv[17];
+        ok = sweep<17>(q, q.hop + HOP_E + r * VPAD, V, epE, lv, 7u);
+        if (ok) {
+          const int Veff = step < sp.eos_mask_steps ? V - 1 : V;
+          float x[17];
+#pragma unroll
+          for (int i = 0; i < 17; ++i) {
+            const int v = q.lane + 64 * i;
+            if (v < V) a.logits_out[(size_t)b * V + v] = __uint_as_float(lv[i]);
+            x[i] = v < Veff ? __uint_as_float(lv[i]) : -INFINITY;
+            if (sp.rep_penalty != 1.0f && v < Veff && seen[v]) x[i] = x[i] < 0.f ? x[i] * sp.rep_penalty : x[i] / sp.rep_penalty;
+          }
+          const float* nrow = nullptr;
+          if (sp.noise) nrow = sp.noise + ((size_t)step * sp.noise_rows + (sp.noise_rows > 1 ? b : 0)) * V;
+          int smp, amx;
+          sample_core<17>(x, Veff, sp.top_k, sp.top_p, sp.temperature, nrow, sp.seed, b, step, &smp, &amx);
+          const bool fin = smp == EOS || amx == EOS;
+          const bool early = (sp.early_stop_num != -1 && (step + 1) > sp.early_stop_num) || step >= sp.max_steps - 1;
+          const int prev_len = sp.P + step;
+          if (q.lane == 0) {
+            if (prev_len < a.ycap) a.ytok[(size_t)b * a.ycap + prev_len] = smp;
+            if (smp >= 0 && smp < VPAD) seen[smp] = 1;
+            if (fin || early) {
+              a.active[b] = 0;
+              sp.out_len[b] = step;
+              atomicSub(a.n_active, 1);
+            } else {
+              sp.out_tokens[(size_t)b * sp.max_steps + step] = smp;
+              a.kv_len[b] = st_kvlen(q)[r] + 1;
+            }
+            a.step_ctr[b] = step + 1;
+          }
+          if (!(fin || early)) {
+            now_active = 1;
+            const int tok = min(max(smp, 0), V - 1);
+            const float* e = a.e_audio + (size_t)tok * D;
+            const float* p = a.pe + (size_t)(sp.P + step) * D;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x0[k] = e[k * 64 + q.lane] + a.alpha_a * p[k * 64 + q.lane];
+          }
+        }
+      }
+      if (ok && s + 1 < a.nsteps) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gstore(q.hop + HOP_A + r * 512 + k * 64 + q.lane, epN, __float_as_uint(x0[k]));
+        if (q.lane == 0) gstore(q.hop + HOP_ST + r, epN, (unsigned)now_active);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
+  Ctx q = c0;
+  unsigned char* smem = c0.smem;
+  const int R = c0.R;
+  const int V = a.V;
+  const int EPS = 4 * a.L + 2;
+  const float scale = rsqrtf((float)HD);
+  // own rows of this member (attention): local rows 2*ro + half, ro = 0, 1
+  auto kv_row_base = [&](int layer, int which, int r) -> const _Float16* {
+    const int b = q.group + MG_GROUPS * r;
+    return a.kv + ((size_t)(layer * 2 + which)) * a.kv_layer_stride + ((size_t)b * NH + q.head) * (size_t)a.smax * HD;
+  };
+  // K/V image of `layer`: st_kvlen + extra cached positions per own row, LDS-DMA, dealt round-robin to the 4 compute waves
+  auto kv_prefetch = [&](int layer, int extra) {
+    int item = 0;
+#pragma unroll
+    for (int ro = 0; ro < 2; ++ro) {
+      const int r = 2 * ro + q.half;
+      if (r >= R || !st_active(q)[r]) continue;
+      const int n = min(st_kvlen(q)[r] + extra, KV_CAP);
+      const int nki = (n + 15) >> 4;
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const _Float16* src = kv_row_base(layer, which, r);
+        const unsigned dst0 = (unsigned)(L_KV + (ro * 2 + which) * KV_CAP * 64);
+        for (int i = 0; i < nki; ++i, ++item) {
+          if ((item & 3) != q.cw) continue;
+          // the arena is allocated to smax positions per (row, head): a partly valid KiB reads allocated memory
+          const int pos = min(16 * i + (q.lane >> 2), a.smax - 1);
+          glds16_nt(src + (size_t)pos * HD + (q.lane & 3) * 8, __builtin_amdgcn_readfirstlane(dst0 + (unsigned)i * 1024u));
+        }
+      }
+    }
+  };
+  const h8* wp = a.wpack;
+  auto p1_src = [&](int layer) { return wp + ((size_t)layer * LAYER_HALFS + ((size_t)q.head * 4 + q.cw) * WI_P1 * 512) / 8 + q.lane; };
+  auto pm_src = [&](int layer, int off) {
+    return wp + ((size_t)layer * LAYER_HALFS + P1_HALFS + (((size_t)q.member * 4 + q.cw) * (WI_P2 + WI_P3 + WI_P4) + off) * 512) / 8 + q.lane;
+  };
+  // P1's slice is held as two halves (tiles q0 q1 k0 | k1 v0 v1): the second half is requested one phase later than the
+  // first, so that FFN2's slice + the whole next P1 slice are never live together (160 + operands would spill)
+  h8 wA0[WI_P1 / 2], wA1[WI_P1 / 2], wB[WI_P2], wC[WI_P3], wD[WI_P4];       // the logits slice reuses wA0
+  kv_prefetch(0, 0);
+  wload(wA0, p1_src(0));
+  wload(wA1, p1_src(0) + (size_t)(WI_P1 / 2) * 64);
+
+  for (int s = 0; s < a.nsteps; ++s) {
+    const unsigned ep0 = (unsigned)s * (unsigned)EPS;
+    for (int l = 0; l < a.L; ++l) {
+      const MegaLayerP lp = a.lp[l];
+      relaunder(q);
+      wload(wB, pm_src(l, 0));
+      // ================= P1: q,k,v of head `head` for the own rows, K/V append, attention
+      f4 p1_bias[2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int task = q.tid_c + 256 * it, tile = task >> 6, ln = task & 63;
+        p1_bias[it] = tile < 6 ? *(const f4*)(lp.qkv_b + (tile >> 1) * D + q.head * HD + 16 * (tile & 1) + 4 * (ln >> 4)) : (f4){0.f, 0.f, 0.f, 0.f};
+      }
+      MG_BAR();                                                          // B1: XS / XRES hold LN(y)
+      if (*st_abort(q)) return;
+      if (l == 0 && s > 0 && group_done(q)) return;
+      gemm_chunk<3>(q, wA0, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 6);
+      gemm_chunk<3>(q, wA1, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 6 + 3);
+      MG_BAR();                                                          // B2
+      {
+        const f4* red = (const f4*)(smem + L_RED);
+        _Float16* qkv_s = (_Float16*)(smem + L_QKV);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int task = q.tid_c + 256 * it, tile = task >> 6, ln = task & 63;
+          const int r = ln & 15;
+          if (tile >= 6 || r >= R || (r & 1) != q.half) continue;
+          f4 v = red[(0 * 6 + tile) * 64 + ln];
+          v += red[(1 * 6 + tile) * 64 + ln];
+          v += red[(2 * 6 + tile) * 64 + ln];
+          v += red[(3 * 6 + tile) * 64 + ln];
+          v += p1_bias[it];
+          const int ro = r >> 1, which = tile >> 1, e = 16 * (tile & 1) + 4 * (ln >> 4);
+          const h4 ov = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+          *(h4*)(qkv_s + (ro * 3 + which) * HD + e) = ov;
+          if (which > 0 && st_active(q)[r]) {
+            const int pos = st_kvlen(q)[r];
+            if (pos < a.smax) *(h4*)(const_cast<_Float16*>(kv_row_base(l, which - 1, r)) + (size_t)pos * HD + e) = ov;
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this layer's K/V image (LDS-DMA) has landed
+      }
+      MG_BAR();                                                          // B3
+      {
+        // attention of own row ro = q.cw >> 1, keys dealt to the two waves of the row in 16-key groups
+        const int ro = q.cw >> 1, hw = q.cw & 1, r = 2 * ro + q.half;
+        const bool rv = r < R && st_active(q)[r];
+        const int n_old = rv ? st_kvlen(q)[r] : 0;
+        const int part = q.lane & 3, slot = q.lane >> 2;
+        const _Float16* qkv_s = (const _Float16*)(smem + L_QKV) + ro * 3 * HD;
+        float qf[8];
+        {
+          const h8 qv = *(const h8*)(qkv_s + part * 8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) qf[i] = (float)qv[i] * scale;
+        }
+        float m = -INFINITY, lsum = 0.f, acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        auto consume = [&](const h8& kk, const h8& vv, bool ok) {
+          float sc = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sc += qf[i] * (float)kk[i];
+          sc += __shfl_xor(sc, 1, 64);
+          sc += __shfl_xor(sc, 2, 64);
+          if (ok) {
+            const float mn = fmaxf(m, sc);
+            const float corr = __expf(m - mn);
+            const float p = __expf(sc - mn);
+            lsum = lsum * corr + p;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = acc[i] * corr + p * (float)vv[i];
+            m = mn;
+          }
+        };
+        const unsigned char* kimg = smem + L_KV + (ro * 2 + 0) * KV_CAP * 64;
+        const unsigned char* vimg = smem + L_KV + (ro * 2 + 1) * KV_CAP * 64;
+        const int n_img = min(n_old, KV_CAP);
+        for (int j0 = hw * 16; j0 < n_img; j0 += 64) {
+          const int ja = j0 + slot, jb = j0 + 32 + slot;
+          const int jac = min(ja, KV_CAP - 1), jbc = min(jb, KV_CAP - 1);
+          const h8 ka = *(const h8*)(kimg + jac * 64 + part * 16), va = *(const h8*)(vimg + jac * 64 + part * 16);
+          const h8 kb = *(const h8*)(kimg + jbc * 64 + part * 16), vb = *(const h8*)(vimg + jbc * 64 + part * 16);
+          consume(ka, va, ja < n_img);
+          consume(kb, vb, jb < n_img);
+        }
+        if (n_old > KV_CAP) {                                            // long rows: the tail comes straight from HBM
+          const _Float16* kg_ = kv_row_base(l, 0, r) + part * 8;
+          const _Float16* vg_ = kv_row_base(l, 1, r) + part * 8;
+          for (int j0 = KV_CAP + hw * 16; j0 < n_old; j0 += 32) {
+            const int j = j0 + slot, jc = min(j, n_old - 1);
+            const h8 kk = __builtin_nontemporal_load((const h8*)(kg_ + (size_t)jc * HD));
+            const h8 vv = __builtin_nontemporal_load((const h8*)(vg_ + (size_t)jc * HD));
+            consume(kk, vv, j < n_old);
+          }
+        }
+        if (hw == 0) {                                                   // this step's own key / value
+          const h8 kk = *(const h8*)(qkv_s + HD + part * 8), vv = *(const h8*)(qkv_s + 2 * HD + part * 8);
+          consume(kk, vv, rv && slot == 0);
+        }
+        const float wm = wave_max(m);
+        const float f = (m == -INFINITY) ? 0.f : __expf(m - wm);
+        lsum *= f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] *= f;
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) {
+          lsum += __shfl_xor(lsum, o, 64);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+        }
+        float* s_m = (float*)(smem + L_ATT);
+        float* s_acc = s_m + 4;
+        if (q.lane < 4) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) s_acc[q.cw * 36 + q.lane * 8 + i] = acc[i];
+          if (q.lane == 0) { s_acc[q.cw * 36 + 32] = lsum; s_m[q.cw] = wm; }
+        }
+      }
+      MG_BAR();                                                          // B4
+      if (q.cw == 0) {
+        const float* s_m = (const float*)(smem + L_ATT);
+        const float* s_acc = s_m + 4;
+        const int ro = q.lane >> 5, e = q.lane & 31, r = 2 * ro + q.half;
+        const float m0 = s_m[2 * ro], m1 = s_m[2 * ro + 1], M = fmaxf(m0, m1);
+        float o = 0.f;
+        if (M != -INFINITY) {
+          const float e0 = m0 == -INFINITY ? 0.f : __expf(m0 - M), e1 = m1 == -INFINITY ? 0.f : __expf(m1 - M);
+          const float Lsum = s_acc[(2 * ro) * 36 + 32] * e0 + s_acc[(2 * ro + 1) * 36 + 32] * e1;
+          o = (s_acc[(2 * ro) * 36 + e] * e0 + s_acc[(2 * ro + 1) * 36 + e] * e1) / Lsum;
+        }
+        const float o2 = __shfl_xor(o, 1, 64);
+        if (r < R && !(e & 1)) gstore(q.hop + HOP_B + r * 256 + (q.head * HD + e) / 2, ep0 + 4 * l + 2, pack_h2(o, o2));
+      }
+      relaunder(q);
+      // next layer's K/V image (the next step's layer 0 will hold one more position: appended above by this CU)
+      if (l + 1 < a.L) kv_prefetch(l + 1, 0);
+      else kv_prefetch(0, 1);
+      wload(wC, pm_src(l, WI_P2));
+      // ================= P2: out-projection columns [16 member, +16) + bias + residual -> y1
+      f4 p_bias = *(const f4*)(lp.out_b + 16 * q.member + 4 * (q.lane >> 4));
+      MG_BAR();                                                          // B1: AT holds the attention output
+      if (*st_abort(q)) return;
+      gemm_chunk<1>(q, wB, (const _Float16*)(smem + L_AT), XS_LD, q.cw, q.cw);
+      MG_BAR();                                                          // B2
+      if (q.cw == 0) {
+        const f4* red = (const f4*)(smem + L_RED);
+        const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
+        if (r < R) {
+          f4 v = red[q.lane];
+          v += red[64 + q.lane]; v += red[128 + q.lane]; v += red[192 + q.lane];
+          v += p_bias;
+          v += *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gstore(q.hop + HOP_C + r * 512 + n0 + i, ep0 + 4 * l + 3, __float_as_uint(v[i]));
+        }
+      }
+      relaunder(q);
+      wload(wD, pm_src(l, WI_P2 + WI_P3));
+      // ================= P3: FFN1 columns [64 member, +64), ReLU -> h
+      p_bias = *(const f4*)(lp.b1 + 64 * q.member + 16 * q.cw + 4 * (q.lane >> 4));
+      MG_BAR();                                                          // B1: XS / XRES hold LN1(y1)
+      if (*st_abort(q)) return;
+      gemm_chunk<4>(q, wC, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 4);
+      MG_BAR();                                                          // B2
+      {
+        const f4* red = (const f4*)(smem + L_RED);
+        const int tile = q.cw, r = q.lane & 15, n0 = 64 * q.member + 16 * tile + 4 * (q.lane >> 4);
+        if (r < R) {
+          f4 v = red[(0 * 4 + tile) * 64 + q.lane];
+          v += red[(1 * 4 + tile) * 64 + q.lane]; v += red[(2 * 4 + tile) * 64 + q.lane]; v += red[(3 * 4 + tile) * 64 + q.lane];
+          v += p_bias;
+          gstore(q.hop + HOP_D + r * 1024 + n0 / 2, ep0 + 4 * l + 4, pack_h2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)));
+          gstore(q.hop + HOP_D + r * 1024 + n0 / 2 + 1, ep0 + 4 * l + 4, pack_h2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)));
+        }
+      }
+      relaunder(q);
+      if (l + 1 < a.L) wload(wA0, p1_src(l + 1));
+      else wload(wA0, a.lpack + (((size_t)q.member * 4 + q.cw) * WI_LG * 512) / 8 + q.lane);
+      // ================= P4: FFN2 columns [16 member, +16) over K = 2048 (16 chunks, summed in chunk order) -> y2
+      p_bias = *(const f4*)(lp.b2 + 16 * q.member + 4 * (q.lane >> 4));
+      MG_BAR();                                                          // B1: HS holds the FFN hidden
+      if (*st_abort(q)) return;
+      {
+        const int rowl = q.lane & 15, kg = q.lane >> 4;
+        f4* red = (f4*)(smem + L_RED);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int kc = 4 * q.cw + cc;
+          const _Float16* bp = (const _Float16*)(smem + L_HS) + (rowl & (RMAX - 1)) * HS_LD + kc * 128 + 8 * kg;
+          f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wD[cc * 4 + ks], *(const h8*)(bp + 32 * ks), acc, 0, 0, 0);
+          red[kc * 64 + q.lane] = acc;
+          __builtin_amdgcn_sched_barrier(0);       // keep the 16 operand reads from being hoisted in front of the first MFMA
+        }
+      }
+      MG_BAR();                                                          // B2
+      if (q.cw == 0) {
+        const f4* red = (const f4*)(smem + L_RED);
+        const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
+        if (r < R) {
+          f4 v = red[q.lane];
+#pragma unroll
+          for (int kc = 1; kc < 16; ++kc) v += red[kc * 64 + q.lane];
+          v += p_bias;
+          v += *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
+          // y2 feeds hop A of the next layer, or hop A' (the logits' LayerNorm) after the last layer
+          const unsigned ep = l + 1 < a.L ? ep0 + 4 * (l + 1) + 1 : ep0 + 4 * a.L + 1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gstore(q.hop + HOP_A + r * 512 + n0 + i, ep, __float_as_uint(v[i]));
+        }
+      }
+      wload(wA1, p1_src(l + 1 < a.L ? l + 1 : 0) + (size_t)(WI_P1 / 2) * 64);   // second half of the next P1 slice
+    }
+    // ================= tail: logits split over the members (tiles member, member + 32, and tile 64 on member 0)
+    const unsigned epE = ep0 + 4 * a.L + 2;
+    relaunder(q);
+    MG_BAR();                                                            // B1: XS holds LN2(y) of the last layer
+    if (*st_abort(q)) return;
+    gemm_chunk<3>(q, wA0, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 3);
+    wload(wA0, p1_src(0));                                               // next step's layer 0 (two hops away; wA1 is already there)
+    MG_BAR();                                                            // B2
+    if (q.cw < 3) {
+      const f4* red = (const f4*)(smem + L_RED);
+      const int t = q.cw, r = q.lane & 15;
+      const int tile = t == 0 ? q.member : (t == 1 ? q.member + 32 : 64);
+      if (r < R && (t < 2 || q.member == 0)) {
+        f4 v = red[(0 * 3 + t) * 64 + q.lane];
+        v += red[(1 * 3 + t) * 64 + q.lane]; v += red[(2 * 3 + t) * 64 + q.lane]; v += red[(3 * 3 + t) * 64 + q.lane];
+        const int n0 = 16 * tile + 4 * (q.lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (n0 + i < V) gstore(q.hop + HOP_E + r * VPAD + n0 + i, epE, __float_as_uint(v[i]));
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Ctx c;
+  c.smem = smem;
+  const int tid = threadIdx.x;
+  c.lane = tid & 63; c.wave = __builtin_amdgcn_readfirstlane(tid >> 6); c.comm = c.wave < 4; c.cw = c.wave & 3; c.tid_c = tid - 256;
+  if (a.map_shared) { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; c.member = xcd * 4 + (slot >> 3); c.group = slot & 7; }
+  else { c.group = blockIdx.x & 7; c.member = blockIdx.x >> 3; }
+  c.head = c.member >> 1; c.half = c.member & 1;
+  c.R = a.B > c.group ? (a.B - c.group + MG_GROUPS - 1) / MG_GROUPS : 0;
+  if (c.R == 0) return;
+  c.hop = (gu64*)a.hop + (size_t)c.group * HOP_GROUP;
+  c.err = (gu32*)a.err;
+  const int lane = c.lane, R = c.R;
+  const StepParams sp = *a.sp;
+
+  // ---- init: zero the activation images, load the row state, build the samplers' seen-map ----
+  for (int i = tid; i < L_RED / 4; i += MG_THREADS) ((unsigned*)smem)[i] = 0u;
+  if (tid < 16) ((int*)(smem + L_ST))[tid] = 0;
+  __syncthreads();
+  if (tid < R) {
+    const int b = c.group + MG_GROUPS * tid;
+    st_active(c)[tid] = a.active[b];
+    st_kvlen(c)[tid] = a.kv_len[b];
+    st_step(c)[tid] = a.step_ctr[b];
+  }
+  if (c.member < R && c.wave == 0) {
+    unsigned char* seen = smem + L_SEEN;
+    for (int v = lane; v < VPAD; v += 64) seen[v] = 0;
+    const int b = c.group + MG_GROUPS * c.member;
+    const int prev_len = sp.P + a.step_ctr[b];
+    const int* yrow = a.ytok + (size_t)b * a.ycap;
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int t = lane; t < prev_len; t += 64) {
+      const int tok = yrow[t];
+      if (tok >= 0 && tok < a.V) seen[tok] = 1;
+    }
+  }
+  __syncthreads();
+  if (group_done(c)) return;
+  if (c.comm) comm_role(a, c, sp);
+  else compute_role(a, c);
+}
+
+// census: are 256 workgroups of the engine's footprint co-resident?  Every workgroup arrives on a counter and waits
+// (bounded) for all of them; a workgroup that gives up reports it.
+__global__ __launch_bounds__(MG_THREADS, 1) void mega_census_kernel(unsigned* ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  smem[threadIdx.x] = 0;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)MG_NWG) {
+      if (++spins > (1u << 20)) { __hip_atomic_fetch_add(ws + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+}
+
+}  // namespace
+
+bool mega_shape_ok(int dim, int n_head, int ffn, int vocab) { return dim == D && n_head == NH && ffn == FF && vocab >= 64 && vocab <= VPAD; }
+size_t mega_layer_pack_halfs() { return LAYER_HALFS; }
+size_t mega_logits_pack_halfs() { return LOGIT_HALFS; }
+size_t mega_hop_bytes() { return (size_t)MG_GROUPS * HOP_GROUP * 8; }
+
+// fragment of one KiB-instruction: lane ln holds W[row0 + (ln & 15)][k0 + 8 (ln >> 4) .. +8]
+static void pack_frag(const float* w, int ldw, int row0, int nrows, int k0, _Float16* dst) {
+  for (int ln = 0; ln < 64; ++ln) {
+    const int row = row0 + (ln & 15), k = k0 + 8 * (ln >> 4);
+    for (int e = 0; e < 8; ++e) dst[ln * 8 + e] = row < nrows ? (_Float16)w[(size_t)row * ldw + k + e] : (_Float16)0.f;
+  }
+}
+
+void mega_pack_layer(const float* qkv_w, const float* out_w, const float* w1, const float* w2, _Float16* dst) {
+  // P1 by head: tiles q0 q1 k0 k1 v0 v1, wave = K chunk of 128, 4 k-steps of 32
+  for (int h = 0; h < NH; ++h)
+    for (int w = 0; w < 4; ++w)
+      for (int t = 0; t < 6; ++t)
+        for (int ks = 0; ks < 4; ++ks)
+          pack_frag(qkv_w, D, (t >> 1) * D + h * HD + 16 * (t & 1), 3 * D, 128 * w + 32 * ks,
+                    dst + (((size_t)h * 4 + w) * WI_P1 + t * 4 + ks) * 512);
+  _Float16* pm = dst + P1_HALFS;
+  const int per = WI_P2 + WI_P3 + WI_P4;
+  for (int j = 0; j < MG_MEMBERS; ++j)
+    for (int w = 0; w < 4; ++w) {
+      _Float16* base = pm + ((size_t)j * 4 + w) * per * 512;
+      for (int ks = 0; ks < 4; ++ks) pack_frag(out_w, D, 16 * j, D, 128 * w + 32 * ks, base + (size_t)ks * 512);
+      for (int t = 0; t < 4; ++t)
+        for (int ks = 0; ks < 4; ++ks)
+          pack_frag(w1, D, 64 * j + 16 * t, FF, 128 * w + 32 * ks, base + (size_t)(WI_P2 + t * 4 + ks) * 512);
+      for (int cc = 0; cc < 4; ++cc)
+        for (int ks = 0; ks < 4; ++ks)
+          pack_frag(w2, FF, 16 * j, D, 128 * (4 * w + cc) + 32 * ks, base + (size_t)(WI_P2 + WI_P3 + cc * 4 + ks) * 512);
+    }
+}
+
+void mega_pack_logits(const float* pred_w, int V, _Float16* dst) {
+  for (int j = 0; j < MG_MEMBERS; ++j)
+    for (int w = 0; w < 4; ++w)
+      for (int t = 0; t < 3; ++t) {
+        const int tile = t == 0 ? j : (t == 1 ? j + 32 : 64);
+        for (int ks = 0; ks < 4; ++ks)
+          pack_frag(pred_w, D, 16 * tile, V, 128 * w + 32 * ks, dst + (((size_t)j * 4 + w) * WI_LG + t * 4 + ks) * 512);
+      }
+}
+
+int mega_census(hipStream_t s, unsigned* d_scratch, unsigned* h_pinned) {
+  GSV_HIP(hipFuncSetAttribute((const void*)mega_census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
+  GSV_HIP(hipMemsetAsync(d_scratch, 0, 16, s));
+  hipLaunchKernelGGL(mega_census_kernel, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, d_scratch);
+  GSV_HIP(hipGetLastError());
+  GSV_HIP(hipMemcpyAsync(h_pinned, d_scratch, 8, hipMemcpyDeviceToHost, s));
+  GSV_HIP(hipStreamSynchronize(s));
+  return (h_pinned[0] == (unsigned)MG_NWG && h_pinned[1] == 0u) ? 1 : 0;
+}
+
+int launch_t2s_mega(const MegaArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(t2s_mega_kernel, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+}  // namespace gsv

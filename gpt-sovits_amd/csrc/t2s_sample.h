@@ -1,0 +1,177 @@
+// AR sampling (H5) shared by the launch-per-phase decode step (t2s.hip) and the persistent decode engine (t2s_mega.hip).
+#pragma once
+#include "common.h"
+
+namespace gsv {
+
+// ---------------------------------------------------------------------------------------
+// device-side parameter block shared by the step kernels (lives in HBM so that the captured
+// graph does not bake sampling parameters)
+// ---------------------------------------------------------------------------------------
+struct StepParams {
+  int top_k;
+  float top_p;
+  float temperature;
+  float rep_penalty;
+  int early_stop_num;
+  int eos_mask_steps;
+  int max_steps;
+  int noise_rows;          // 0: counter RNG, 1: shared noise, B: per-row noise
+  unsigned long long seed;
+  const float* noise;      // [max_steps][noise_rows][V] or null
+  int* out_tokens;         // [B][max_steps]
+  int* out_len;            // [B]
+  int P;                   // prompt length (position offset of generated tokens)
+};
+
+
+// ---------------------------------------------------------------------------------------
+// Sampling (H5): one wave per row, the whole row in registers (NPL values per lane), all
+// reductions are wavefront shuffles.  Semantics follow reference AR/models/utils.py:147-199:
+// repetition penalty (in place, so the EOS argmax test of t2s_model.py:721 sees penalised
+// logits) -> top-p on the un-tempered distribution -> /temperature -> top-k (ties kept) ->
+// softmax -> argmax(p / Exp(1)).  No sort: tokens are extracted in descending order only as
+// far as top-k / top-p need.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+struct ArgMax { float v; int i; };
+__device__ __forceinline__ ArgMax wave_argmax(float v, int i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+  return {v, i};
+}
+
+// everything after the repetition penalty: x[] holds the (penalised) logits of this lane's tokens v = lane + 64 i
+template <int NPL>
+__device__ __forceinline__ void sample_core(float (&x)[NPL], int Veff, int top_k, float top_p, float temperature,
+                                            const float* __restrict__ noise_row, unsigned long long seed, int row, int step,
+                                            int* out_sample, int* out_argmax) {
+  const int lane = threadIdx.x & 63;
+  // argmax of the penalised logits (first index on ties)
+  float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int v = lane + 64 * i;
+    if (v < Veff && (x[i] > bv)) { bv = x[i]; bi = v; }
+  }
+  ArgMax am = wave_argmax(bv, bi);
+  *out_argmax = am.i;
+  const float max0 = am.v;
+
+  const bool use_p = top_p < 1.0f;
+  const bool use_k = top_k > 0 && top_k < Veff;
+  unsigned int keep = 0;  // bit i: x[i] survives the filters
+  if (!use_p && !use_k) {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) if (lane + 64 * i < Veff) keep |= 1u << i;
+  } else {
+    float S = 1.f;
+    if (use_p) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) if (lane + 64 * i < Veff) s += expf(x[i] - max0);
+      S = wave_sum(s);
+    }
+    unsigned int taken = 0;
+    float cum = 0.f, pivot = 0.f;
+    bool have_pivot = false;
+    for (int r = 0; r < Veff; ++r) {
+      float cv = -INFINITY; int ci = 0x7fffffff; int cslot = -1;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int v = lane + 64 * i;
+        if (v < Veff && !((taken >> i) & 1u) && x[i] > cv) { cv = x[i]; ci = v; cslot = i; }
+      }
+      ArgMax e = wave_argmax(cv, ci);
+      if (e.i == 0x7fffffff || e.v == -INFINITY) break;  // nothing finite left
+      bool kept = true;
+      if (use_p) {
+        cum += expf(e.v - max0) / S;
+        if (r > 0 && cum > top_p) kept = false;
+      }
+      if (!kept) break;                  // top-p removes this and everything after it
+      if (use_k) {
+        if (r == top_k - 1) { pivot = e.v; have_pivot = true; }
+        else if (r >= top_k && !(have_pivot && e.v == pivot)) break;  // past the k-th value and not a tie
+      }
+      if (ci == e.i && cslot >= 0) {
+        // the owning lane marks the token as taken and kept
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) if (i == cslot) { taken |= 1u << i; keep |= 1u << i; }
+      }
+    }
+  }
+  // softmax over the kept set at temperature T, then the exponential race
+  const float tdiv = fmaxf(temperature, 1e-5f);
+  float lm = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) if ((keep >> i) & 1u) lm = fmaxf(lm, x[i] / tdiv);
+  lm = wave_max(lm);
+  float z = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) if ((keep >> i) & 1u) z += expf(x[i] / tdiv - lm);
+  z = wave_sum(z);
+  float sv = -INFINITY; int si = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int v = lane + 64 * i;
+    // filtered-out tokens have p = 0 and score 0 / q = 0: they can only win when no kept token has a
+    // positive score, which cannot happen (rank 0 is always kept), so their Exp(1) draw is never needed
+    if (v >= Veff || !((keep >> i) & 1u)) continue;
+    float p = expf(x[i] / tdiv - lm) / z;
+    float qn;
+    if (noise_row) qn = noise_row[v];
+    else {
+      unsigned long long hsh = splitmix64(seed ^ splitmix64(((unsigned long long)row << 40) ^ ((unsigned long long)step << 20) ^ (unsigned long long)v));
+      float u = (float)(hsh >> 40) * (1.0f / 16777216.0f);
+      qn = fmaxf(-log1pf(-u), 1e-20f);
+    }
+    float sc = p / qn;
+    if (sc > sv || (sc == sv && v < si)) { sv = sc; si = v; }
+  }
+  ArgMax sm = wave_argmax(sv, si);
+  *out_sample = sm.i;
+}
+
+
+template <int NPL>
+__device__ void sample_row(const float* __restrict__ lg_row, int V, int Veff, const int* __restrict__ prev, int prev_len,
+                           int top_k, float top_p, float temperature, float rp, const float* __restrict__ noise_row,
+                           unsigned long long seed, int row, int step, unsigned char* seen /* LDS [V] */,
+                           int* out_sample, int* out_argmax) {
+  const int lane = threadIdx.x & 63;
+  float x[NPL];
+  // token v = lane + 64*i  (coalesced loads, low index first inside a lane)
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int v = lane + 64 * i;
+    x[i] = (v < Veff) ? lg_row[v] : -INFINITY;
+  }
+  if (rp != 1.0f) {
+    for (int v = lane; v < V; v += 64) seen[v] = 0;
+    __syncthreads();
+    for (int t = lane; t < prev_len; t += 64) {
+      int tok = prev[t];
+      if (tok >= 0 && tok < V) seen[tok] = 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int v = lane + 64 * i;
+      if (v < Veff && seen[v]) x[i] = (x[i] < 0.f) ? x[i] * rp : x[i] / rp;
+    }
+  }
+  sample_core<NPL>(x, Veff, top_k, top_p, temperature, noise_row, seed, row, step, out_sample, out_argmax);
+}
+
+}  // namespace gsv

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import warnings
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -107,10 +108,11 @@ class Text2SemanticDecoder:
             lens = [int(t.shape[-1]) for t in x]
             P = int(prompts.shape[1])
             need = max(lens) + P + 2
-            budget = max_steps if early_stop_num in (-1, None) else min(max_steps, int(early_stop_num) + 1)
-            budget = min(budget, self.max_seq - need)
+            wanted = max_steps if early_stop_num in (-1, None) else min(max_steps, int(early_stop_num) + 1)
+            budget = min(wanted, self.max_seq - need)
             if budget < 1:
                 raise ValueError(f"sequence of {need} positions does not fit max_seq={self.max_seq}")
+            arena_bound = budget < wanted
             phones = torch.cat([t.reshape(-1) for t in x]).to(dev, torch.int32).contiguous()
             lens_h = (C.c_int32 * B)(*lens)
             bert_dev = None
@@ -151,6 +153,13 @@ class Text2SemanticDecoder:
             self.last_steps = steps.value
             y_all = torch.cat([pr, out_tokens], dim=1).long()       # one concat for the batch; rows are sliced as views
             y_list = []
+            self.last_truncated = [b for b in range(B) if idx[b] < 0] if arena_bound else []
+            if self.last_truncated:
+                # the reference always allows 1500 steps (t2s_model.py:694) or early_stop_num; here the K/V arena ended
+                # these rows first -- never silently
+                warnings.warn(f"Text2SemanticDecoder: rows {self.last_truncated} were cut after {steps.value - 1} tokens by the "
+                              f"K/V arena (max_seq={self.max_seq}, {need} positions used by text + prompt); create the "
+                              f"decoder with a larger max_seq", RuntimeWarning, stacklevel=3)
             for b in range(B):
                 n = idx[b] if idx[b] >= 0 else steps.value - 1
                 idx[b] = n
@@ -209,6 +218,18 @@ class Text2SemanticDecoder:
             y_list.append(y[0])
             idx_list.append(idx)
         return y_list, idx_list
+
+    # ---- decode-engine selection / report -------------------------------------------
+    def set_mega(self, on: bool):
+        """A/B switch: False makes later calls use the launch-per-phase decode step instead of the persistent engine
+        (csrc/t2s_mega.hip; fp16, v1/v2 shape, batch <= 32)."""
+        _lib.check(_lib.lib().gsv_t2s_set_mega(self._h, int(bool(on))), "gsv_t2s_set_mega")
+
+    def decode_info(self):
+        """(mode, device_ms, steps) of the last decode call: mode 1 = persistent engine, 0 = launch per phase."""
+        mode, ms, steps = C.c_int(0), C.c_float(0), C.c_int(0)
+        _lib.check(_lib.lib().gsv_t2s_decode_info(self._h, C.byref(mode), C.byref(ms), C.byref(steps)), "gsv_t2s_decode_info")
+        return mode.value, ms.value, steps.value
 
     # ---- measurement hooks (bench.py) ----------------------------------------------
     def debug_logits(self, B: int) -> torch.Tensor:

@@ -76,7 +76,9 @@ class TTS_Config:
         self.t2s_weights_path = configs.get("t2s_weights_path")
         self.vits_weights_path = configs.get("vits_weights_path")
         self.max_batch = int(configs.get("max_batch", 32))
-        self.max_seq = int(configs.get("max_seq", 2048))
+        # K/V arena positions per row: the reference's 1500-step loop (t2s_model.py:694) + a 10 s prompt (250 tokens)
+        # + phonemes of prompt and text; 2560 x 32 rows x 24 layers is 4 GB of fp16 K/V
+        self.max_seq = int(configs.get("max_seq", 2560))
         self.use_vocoder = self.version in ("v3", "v4")     # TTS.py:519-521
         self.max_sec = None
         self.hz: int = 50
@@ -198,7 +200,11 @@ class TTS:
         # TTS.py:790-800 keeps it beside the spectrogram); computing it is the ERes2NetV2 front-end, outside this build
         self.prompt_cache["sv_emb"] = list(sv_emb) if sv_emb is not None else None
         self.prompt_cache["prompt_semantic"] = prompt_semantic.to(self.configs.device) if prompt_semantic is not None else None
-        self.prompt_cache["refer_spec"] = [(s, None) for s in refer_spec]
+        # the spectrograms go to the device ONCE here (the engine caches the style vector per reference and keys the
+        # cache on these tensors), and a new prompt always drops the engine's cached reference terms
+        self.prompt_cache["refer_spec"] = [(s.to(self.configs.device), None) for s in refer_spec]
+        if self.vits_model is not None:
+            self.vits_model.invalidate_refer()
         self.prompt_cache["phones"] = phones
         self.prompt_cache["bert_features"] = bert_features
         self.prompt_cache["norm_text"] = norm_text

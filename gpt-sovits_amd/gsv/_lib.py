@@ -63,6 +63,8 @@ _SIGS = {
                                   C.c_void_p]),
     "gsv_t2s_decode": (C.c_int, [C.c_void_p, C.POINTER(SamplingParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_int), C.c_void_p]),
+    "gsv_t2s_decode_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "gsv_t2s_set_mega": (C.c_int, [C.c_void_p, C.c_int]),
     "gsv_t2s_debug_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsv_t2s_time_step": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]),
     "gsv_t2s_debug_set_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

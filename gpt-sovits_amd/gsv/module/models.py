@@ -69,6 +69,7 @@ class SynthesizerTrn:
             self.stream = torch.cuda.Stream(device=self.device)
         self._loaded = False
         self._ref_key = None
+        self._ref_hold = None
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -109,6 +110,9 @@ class SynthesizerTrn:
                 raise ValueError("sv_emb: expected one [1, 20480] tensor per reference spectrogram")
         elif sv_emb is not None:
             raise ValueError("sv_emb is only used by v2Pro / v2ProPlus models")
+        # The key is (address, shape, version) of the caller's tensors; the tensors themselves are held in `_ref_hold`
+        # for as long as the key is live, so the caching allocator cannot hand the same address to a different
+        # reference spectrogram (the reference recomputes ge from the content on every decode, models.py:966-975).
         key = tuple((r.data_ptr(), tuple(r.shape), r._version) for r in refs + (svs or []))
         if key == self._ref_key:
             return
@@ -116,16 +120,24 @@ class SynthesizerTrn:
         ptrs = (C.c_void_p * len(keep))(*[r.data_ptr() for r in keep])
         frames = (C.c_int * len(keep))(*[int(r.shape[2]) for r in keep])
         bins = int(keep[0].shape[1])
+        keep_sv = [v.reshape(-1).to(self.device, torch.float32).contiguous() for v in svs] if svs is not None else None
+        # engine stream waits for the conversions above (they run on torch's current stream)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         if svs is None:
             _lib.check(_lib.lib().gsv_vits_set_refer(self._h, ptrs, frames, bins, len(keep),
                                                      C.c_void_p(self.stream.cuda_stream)), "gsv_vits_set_refer")
         else:
-            keep_sv = [v.reshape(-1).to(self.device, torch.float32).contiguous() for v in svs]
             sv_ptrs = (C.c_void_p * len(keep_sv))(*[v.data_ptr() for v in keep_sv])
             _lib.check(_lib.lib().gsv_vits_set_refer_sv(self._h, ptrs, frames, bins, sv_ptrs, len(keep),
                                                         C.c_void_p(self.stream.cuda_stream)), "gsv_vits_set_refer_sv")
         self.stream.synchronize()
         self._ref_key = key
+        self._ref_hold = refs + (svs or [])
+
+    def invalidate_refer(self):
+        """Forget the cached reference-audio terms (called by TTS.set_prompt_cache / set_ref_audio)."""
+        self._ref_key = None
+        self._ref_hold = None
 
     @torch.no_grad()
     def decode(self, codes: torch.Tensor, text: torch.Tensor, refer, noise_scale: float = 0.5, speed: float = 1,
@@ -141,7 +153,6 @@ class SynthesizerTrn:
         L = int(text.shape[-1])
         up = math.prod(self.upsample_rates)
         with torch.cuda.device(self.device):
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             self._set_refer(refer, sv_emb)
             cd = codes.reshape(-1).to(self.device, torch.int32).contiguous()
             tx = text.reshape(-1).to(self.device, torch.int32).contiguous()
@@ -150,6 +161,8 @@ class SynthesizerTrn:
             if noise is not None:
                 nz = noise.reshape(self.inter_channels, frames).to(self.device, torch.float32).contiguous()
             wav = torch.empty(frames * up, dtype=torch.float32, device=self.device)
+            # after every conversion above: they are enqueued on torch's current stream, the engine reads on its own
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             _lib.check(_lib.lib().gsv_vits_decode(self._h, cd.data_ptr(), T, tx.data_ptr(), L,
                                                   nz.data_ptr() if nz is not None else None, float(noise_scale),
                                                   float(speed), int(seed) & 0xFFFFFFFFFFFFFFFF, wav.data_ptr(),
@@ -164,10 +177,10 @@ class SynthesizerTrn:
             raise RuntimeError("load_state_dict() first")
         T50 = int(x.shape[-1])
         with torch.cuda.device(self.device):
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             xs = x.reshape(768, T50).to(self.device, torch.float32).contiguous()
             n = (T50 - 2) // 2 + 1
             out = torch.empty(n, dtype=torch.int32, device=self.device)
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             _lib.check(_lib.lib().gsv_vits_extract_latent(self._h, xs.data_ptr(), T50, out.data_ptr(),
                                                           C.c_void_p(self.stream.cuda_stream)), "gsv_vits_extract_latent")
             self.stream.synchronize()
@@ -226,7 +239,6 @@ class SynthesizerTrnV3(SynthesizerTrn):
         T, L = int(codes.shape[-1]), int(text.shape[-1])
         l = _lib.lib()
         with torch.cuda.device(self.device):
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             if ge is None or ge != self._ref_key:
                 self._set_refer(refer)
             F_ = l.gsv_vits_encp_frames(self._h, T, float(speed))
@@ -235,6 +247,7 @@ class SynthesizerTrnV3(SynthesizerTrn):
             cd = codes.reshape(-1).to(self.device, torch.int32).contiguous()
             tx = text.reshape(-1).to(self.device, torch.int32).contiguous()
             fea = torch.empty(512, F_, dtype=torch.float32, device=self.device)
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             _lib.check(l.gsv_vits_decode_encp(self._h, cd.data_ptr(), T, tx.data_ptr(), L, float(speed), fea.data_ptr(),
                                               C.c_void_p(self.stream.cuda_stream)), "gsv_vits_decode_encp")
             self.stream.synchronize()
@@ -308,11 +321,11 @@ class CFM:
             raise ValueError(f"noise must have shape {(B, self.in_channels, T)}")
         dev = dit.device
         with torch.cuda.device(dev):
-            dit.stream.wait_stream(torch.cuda.current_stream(dev))
             m = mu.to(dev, torch.float32).contiguous()
             p = prompt.to(dev, torch.float32).contiguous()
             nz = noise.to(dev, torch.float32).contiguous() if noise is not None else None
             out = torch.empty(B, self.in_channels, T, dtype=torch.float32, device=dev)
+            dit.stream.wait_stream(torch.cuda.current_stream(dev))
             _lib.check(_lib.lib().gsv_cfm_inference(dit._h, m.data_ptr(), p.data_ptr() if Tp else None, B, T, Tp, int(n_timesteps),
                                                     nz.data_ptr() if nz is not None else None, float(temperature), int(seed),
                                                     out.data_ptr(), C.c_void_p(dit.stream.cuda_stream)), "gsv_cfm_inference")

@@ -73,9 +73,9 @@ class _VocoderEngine:
             raise ValueError(f"expected mel of shape [1, {self.in_channels}, F>=1], got {tuple(mel.shape)}")
         F_ = int(mel.shape[2])
         with torch.cuda.device(self.device):
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             m = mel[0].to(self.device, torch.float32).contiguous()
             wav = torch.empty(F_ * math.prod(self.upsample_rates), dtype=torch.float32, device=self.device)
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))   # after the conversion above
             _lib.check(_lib.lib().gsv_vocoder_forward(self._h, m.data_ptr(), F_, wav.data_ptr(),
                                                       C.c_void_p(self.stream.cuda_stream)), "gsv_vocoder_forward")
             self.stream.synchronize()

@@ -91,7 +91,14 @@ int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_le
 int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noise, int noise_rows,
                    int32_t* out_tokens, int32_t* out_len, int* steps_run, gsv_stream_t stream);
 
-/* test hooks: logits of the last completed step [dev] fp32 [B][vocab] */
+/* How the last gsv_t2s_decode call ran: mode 1 = the persistent engine (csrc/t2s_mega.hip: fp16, d=512/16 heads/FFN 2048,
+ * B <= 32; all steps after step 0 in ONE launch, hand-offs on the chip), mode 0 = one hipGraph of 122 launches per step
+ * (fp32, other shapes, GSV_T2S_NO_MEGA=1, or a device on which the engine's 256 workgroups are not co-resident);
+ * device_ms = HIP-event time of the persistent launch, steps = decode steps it covered (mode 1 only). */
+int gsv_t2s_decode_info(gsv_t2s_t* h, int* mode, float* device_ms, int* steps);
+/* A/B switch inside one process: on = 0 makes later decode calls of this handle use the launch-per-phase step */
+int gsv_t2s_set_mega(gsv_t2s_t* h, int on);
+/* test hooks: logits of the last completed step [dev] fp32 [B][vocab] (launch-per-phase path and step 0 only) */
 int gsv_t2s_debug_logits(gsv_t2s_t* h, float* out, gsv_stream_t stream);
 /* per-kernel timing of the decode step: average device time (ms) of one step over `iters`
  * replays at the current cache length, and of the decode-attention kernel alone. */

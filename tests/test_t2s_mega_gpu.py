@@ -1,0 +1,213 @@
+"""GPU: the persistent AR decode engine (csrc/t2s_mega.hip) against the launch-per-phase step of the same library, against
+the fp32 engine (whose ids are bit-exact vs the reference goldens, test_t2s_gpu.py) and against the reference goldens.
+
+The persistent engine is fp16 (production dtype).  fp16 ids cannot be bit-exact vs the fp32 reference (greedy argmax flips
+on near-ties), so the bars are: (1) one full pass (24 layers + logits) from identical inputs gives logits within 3e-2 of
+the launch path's fp16 logits and 6e-2 of the fp32 engine's; (2) free-running ids equal the reference golden while the
+golden top-2 margin is clear (same bar as the launch path); (3) engine vs launch path over the BASELINE config-2 workload:
+rows identical or diverging only after a long common prefix, agreement rate printed; (4) ragged batches with EOS finishes,
+every batch size 1..32, injected-noise sampling: same finishing bookkeeping as the launch path.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import cases
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _engine(cfg, sd, dtype=torch.float16, max_batch=32, max_seq=512):
+    from gsv.AR.models.t2s_model import Text2SemanticDecoder
+    m = Text2SemanticDecoder(cfg, device=DEV, dtype=dtype, max_batch=max_batch, max_seq=max_seq)
+    m.load_state_dict(sd)
+    return m
+
+
+def _v2(seed=0, suppress_eos=True):
+    from gsv import synthetic as S
+    cfg = S.T2S_V2_CONFIG
+    return cfg, S.make_t2s_state_dict(cfg, seed=seed, suppress_eos=suppress_eos)
+
+
+def _batch(n, seed=0):
+    from gsv import synthetic as S
+    utt = S.make_utterances(n, seed=seed)
+    xs = [torch.tensor(it["all_phones"], device=DEV) for it in utt["items"]]
+    berts = [it["bert"].to(DEV) for it in utt["items"]]
+    prompts = utt["prompt_semantic"].unsqueeze(0).expand(n, -1).contiguous().to(DEV)
+    return xs, berts, prompts
+
+
+def _common_prefix(a, b):
+    n = 0
+    while n < min(len(a), len(b)) and a[n] == b[n]:
+        n += 1
+    return n
+
+
+@pytest.fixture(scope="module")
+def v2_engine():
+    cfg, sd = _v2()
+    return _engine(cfg, sd)
+
+
+def test_engine_is_selected_and_reports_it(v2_engine):
+    eng = v2_engine
+    xs, berts, prompts = _batch(8)
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, early_stop_num=6, repetition_penalty=1.35)
+    eng.set_mega(True)
+    ys, idx = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    mode, ms, steps = eng.decode_info()
+    assert mode == 1 and steps == 6 and ms > 0, "the persistent engine must run for fp16 / v2 shape / B <= 32 on an MI355X"
+    assert idx == [6] * 8
+    eng.set_mega(False)
+    ys0, idx0 = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    assert eng.decode_info()[0] == 0
+    eng.set_mega(True)
+    assert idx0 == idx
+
+
+@pytest.mark.parametrize("B", [1, 3, 8, 32])
+def test_one_pass_logits_match_launch_path_and_fp32(v2_engine, B):
+    """early_stop_num = 1: step 0 (shared kernels) + ONE decode step through each path from identical state."""
+    eng = v2_engine
+    xs, berts, prompts = _batch(B)
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, early_stop_num=1, repetition_penalty=1.35)
+    eng.set_mega(True)
+    ya, _ = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    assert eng.decode_info()[0] == 1
+    la = eng.debug_logits(B).cpu().numpy()
+    eng.set_mega(False)
+    yb, _ = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    lb = eng.debug_logits(B).cpu().numpy()
+    eng.set_mega(True)
+    assert np.isfinite(la).all()
+    err = np.abs(la - lb).max()
+    print(f"[mega] B={B}: one-pass logits vs launch path max-abs {err:.3e} (|logits| max {np.abs(lb).max():.1f})")
+    assert err < 3e-2
+    cfg, sd = _v2()
+    e32 = _engine(cfg, sd, dtype=torch.float32, max_batch=max(B, 1), max_seq=320)
+    e32.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    l32 = e32.debug_logits(B).cpu().numpy()
+    assert np.abs(la - l32).max() < 6e-2
+
+
+def test_golden_v2_ids_on_clear_margins():
+    """ragged 24-layer case with EOS bookkeeping: ids equal the reference golden while its top-2 margin > 0.25."""
+    name = "t2s_v2_greedy"
+    case = cases.T2S_CASES[name]
+    cfg, sd, xs, berts, prompts, noise = cases.t2s_case_inputs(case)
+    g = load_golden(name)
+    eng = _engine(cfg, sd, max_batch=8, max_seq=256)
+    ys, idxs = eng.infer_panel_batch_infer([x.to(DEV) for x in xs], None, prompts.to(DEV), [b.to(DEV) for b in berts],
+                                           top_k=1, top_p=1.0, temperature=1.0, early_stop_num=case["early_stop"],
+                                           repetition_penalty=case["rep"])
+    assert eng.decode_info()[0] == 1
+    margins = g["min_top2_margin"]
+    o, gold = 0, []
+    for n in g["y_lens"]:
+        gold.append(g["y_flat"][o:o + n])
+        o += n
+    P = prompts.shape[1]
+    for a, b in zip(ys, gold):
+        a = a.cpu().tolist()
+        n = 0
+        while n < min(len(a), len(b)) - P and margins[n] > 0.25:
+            n += 1
+        assert a[: P + n] == b[: P + n].tolist()
+
+
+def test_config2_workload_agreement_with_launch_path_and_fp32(v2_engine):
+    """BASELINE configs[1]: B = 32 x (80 phonemes, 100 prompt tokens), 100 generated tokens, greedy.  Reports the
+    free-running token agreement engine vs launch path (both fp16) and engine vs fp32 engine."""
+    eng = v2_engine
+    xs, berts, prompts = _batch(32)
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, early_stop_num=100, repetition_penalty=1.35)
+    eng.set_mega(True)
+    ya, ia = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    assert eng.decode_info()[0] == 1
+    ya2, _ = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    assert [t.tolist() for t in ya] == [t.tolist() for t in ya2], "the engine must be deterministic"
+    eng.set_mega(False)
+    yb, ib = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    eng.set_mega(True)
+    assert ia == [100] * 32 and ib == ia
+    cfg, sd = _v2()
+    e32 = _engine(cfg, sd, dtype=torch.float32, max_batch=32, max_seq=320)
+    yc, _ = e32.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    P = prompts.shape[1]
+    pa = [_common_prefix(a.tolist()[P:], b.tolist()[P:]) for a, b in zip(ya, yb)]
+    pc = [_common_prefix(a.tolist()[P:], c.tolist()[P:]) for a, c in zip(ya, yc)]
+    pbc = [_common_prefix(b.tolist()[P:], c.tolist()[P:]) for b, c in zip(yb, yc)]
+    print(f"[mega] config-2 free-running agreement over 32 x 100 tokens: engine vs launch path {sum(pa)}/3200 common-prefix "
+          f"tokens ({sum(p == 100 for p in pa)}/32 rows identical); engine vs fp32 {sum(pc)}/3200 "
+          f"({sum(p == 100 for p in pc)}/32 rows); launch path vs fp32 {sum(pbc)}/3200 ({sum(p == 100 for p in pbc)}/32 rows)")
+    for y in ya:
+        assert y.shape[0] == P + 100 and int(y.max()) < 1024 and int(y.min()) >= 0
+    # the two fp16 paths share every GEMM's summation order; only attention and LayerNorm reduce in a different order
+    assert sum(pa) >= 0.5 * 3200
+    # against fp32 the engine must do no worse than the launch path does (same dtype, same rounding points)
+    assert sum(pc) >= 0.8 * sum(pbc) - 100
+
+
+@pytest.mark.parametrize("B", [1, 2, 5, 9, 17, 31])
+def test_eos_finishes_ragged_rows_every_batch_size(B):
+    """weights that DO emit EOS, sampling with injected noise: rows finish at different steps; finishing bookkeeping (idx,
+    lengths, token ranges) must be self-consistent and, for rows whose ids agree with the launch path, identical."""
+    cfg, sd = _v2(seed=3, suppress_eos=False)
+    eng = _engine(cfg, sd, max_batch=32, max_seq=400)
+    from gsv import synthetic as S
+    utt = S.make_utterances(B)
+    g = torch.Generator().manual_seed(B)
+    xs = []
+    for i, it in enumerate(utt["items"]):
+        n = 20 + int(torch.randint(0, 60, (1,), generator=g))
+        xs.append(torch.tensor(it["all_phones"][:n], device=DEV))
+    berts = [it["bert"][:, : x.shape[0]].to(DEV) for it, x in zip(utt["items"], xs)]
+    prompts = utt["prompt_semantic"].unsqueeze(0).expand(B, -1).contiguous().to(DEV)
+    noise = torch.empty(64, B, 1025).exponential_(1, generator=g).clamp_min(1e-10)
+    kw = dict(top_k=15, top_p=1.0, temperature=1.0, early_stop_num=60, repetition_penalty=1.35, noise=noise)
+    eng.set_mega(True)
+    ya, ia = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    assert eng.decode_info()[0] == 1
+    eng.set_mega(False)
+    yb, ib = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    P = prompts.shape[1]
+    same = 0
+    for a, b, na, nb in zip(ya, yb, ia, ib):
+        assert a.shape[0] == P + na and 0 <= na <= 60
+        assert int(a[P:].max().item() if na else 0) < 1025
+        if a.tolist() == b.tolist():
+            same += 1
+            assert na == nb
+    print(f"[mega] B={B}: {same}/{B} rows identical to the launch path; finish steps {ia}")
+    assert same >= (B + 1) // 2
+
+
+def test_direct_abi_refuses_budget_beyond_arena():
+    """gsv_t2s_decode through ctypes with max_steps that does not fit the K/V arena returns an error code, not tokens."""
+    import ctypes as C
+    from gsv import _lib
+    cfg, sd = _v2()
+    eng = _engine(cfg, sd, max_batch=4, max_seq=256)
+    xs, berts, prompts = _batch(2)
+    phones = torch.cat(xs).to(DEV, torch.int32)
+    lens = (C.c_int32 * 2)(*[int(x.shape[0]) for x in xs])
+    pr = prompts.to(DEV, torch.int32).contiguous()
+    P = int(pr.shape[1])
+    s = C.c_void_p(eng.stream.cuda_stream)
+    l = _lib.lib()
+    _lib.check(l.gsv_t2s_prefill(eng._h, phones.data_ptr(), C.cast(lens, C.c_void_p), 2, None, pr.data_ptr(), P, s))
+    room = 256 - (max(int(x.shape[0]) for x in xs) + P)
+    out = torch.zeros(2, 1500, dtype=torch.int32, device=DEV)
+    ol = torch.zeros(2, dtype=torch.int32, device=DEV)
+    steps = C.c_int(0)
+    sp = _lib.SamplingParams(1, 1.0, 1.0, 1.35, -1, 1, room + 1, 0)
+    rc = l.gsv_t2s_decode(eng._h, C.byref(sp), None, 0, out.data_ptr(), ol.data_ptr(), C.byref(steps), s)
+    assert rc == -1 and b"arena" in l.gsv_last_error().lower()
+    sp = _lib.SamplingParams(1, 1.0, 1.0, 1.35, -1, 1, room, 0)
+    _lib.check(l.gsv_t2s_decode(eng._h, C.byref(sp), None, 0, out.data_ptr(), ol.data_ptr(), C.byref(steps), s))
+    assert steps.value == room
