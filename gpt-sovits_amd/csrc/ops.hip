@@ -103,6 +103,76 @@ int launch_layernorm(int dtype, const void* x, int x_f32, const void* res, int r
   return GSV_ERR_ARG;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Reference-audio front-end helpers: framing of a waveform into a GEMM operand, STFT
+// magnitude, per-channel normalisation over time (HuBERT's GroupNorm(512, 512)).  The GEMMs themselves are conv_gemm.
+// ---------------------------------------------------------------------------------------------------------------
+// out[t][k] = x[reflect(t * hop + k - pad)] for k < flen, 0 for flen <= k < ld   (torch.stft / F.pad(mode="reflect") framing;
+// pad = 0: plain strided frames, the operand of a Conv1d(1, C, flen, stride = hop))
+template <typename T>
+__global__ void frame_kernel(const float* __restrict__ x, int n, int flen, int hop, int pad, int ld, int T_out, T* __restrict__ out) {
+  const int t = blockIdx.x;
+  if (t >= T_out) return;
+  for (int k = threadIdx.x; k < ld; k += blockDim.x) {
+    float v = 0.f;
+    if (k < flen) {
+      int i = t * hop + k - pad;
+      if (i < 0) i = -i;                       // reflect without repeating the edge sample
+      if (i >= n) i = 2 * (n - 1) - i;
+      v = (i >= 0 && i < n) ? x[i] : 0.f;
+    }
+    out[(long long)t * ld + k] = (T)v;
+  }
+}
+
+// spec[b][t] = sqrt(re^2 + im^2 + eps), ri [T][2 * bins] (re | im column blocks) -> spec [bins][T]  (mel_processing.py:73)
+__global__ void magnitude_kernel(const float* __restrict__ ri, int T, int bins, float eps, float* __restrict__ spec) {
+  __shared__ float tile[32][33];
+  const int t0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, b = b0 + tx;
+    float v = 0.f;
+    if (t < T && b < bins) {
+      const float re = ri[(long long)t * 2 * bins + b], im = ri[(long long)t * 2 * bins + bins + b];
+      v = sqrtf(re * re + im * im + eps);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int b = b0 + i, t = t0 + tx;
+    if (b < bins && t < T) spec[(long long)b * T + t] = tile[tx][i];
+  }
+}
+
+// y[t][c] = act((x[t][c] - mean_c) * rstd_c * gamma[c] + beta[c]), statistics over t (biased variance), channels-last.
+// Two kernels: per-(channel block, time slice) partial sums -> finalize + apply.
+template <typename T>
+__global__ void cnorm_stats_kernel(const T* __restrict__ x, int Tn, int C, int slices, float* __restrict__ part /*[slices][2][C]*/) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, sl = blockIdx.y;
+  if (c >= C) return;
+  const int per = (Tn + slices - 1) / slices, t0 = sl * per, t1 = min(Tn, t0 + per);
+  float s = 0.f, q = 0.f;
+  for (int t = t0; t < t1; ++t) { const float v = to_f(x[(long long)t * C + c]); s += v; q += v * v; }
+  part[((long long)sl * 2 + 0) * C + c] = s;
+  part[((long long)sl * 2 + 1) * C + c] = q;
+}
+template <typename T>
+__global__ void cnorm_apply_kernel(const T* __restrict__ x, int Tn, int C, int slices, const float* __restrict__ part,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act, T* __restrict__ y) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int sl = 0; sl < slices; ++sl) { s += part[((long long)sl * 2 + 0) * C + c]; q += part[((long long)sl * 2 + 1) * C + c]; }
+  const float mean = (float)(s / Tn);
+  const float var = fmaxf((float)(q / Tn - (s / Tn) * (s / Tn)), 0.f);
+  const float a = rsqrtf(var + eps) * gamma[c], b = beta[c] - mean * a;
+  const int per = (Tn + gridDim.y - 1) / gridDim.y, t0 = blockIdx.y * per, t1 = min(Tn, t0 + per);
+  for (int t = t0; t < t1; ++t) y[(long long)t * C + c] = (T)post_act_f(act, to_f(x[(long long)t * C + c]) * a + b);
+}
+
 }  // namespace gsv
 
 extern "C" {
@@ -167,7 +237,44 @@ int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream) {
   if (d->ldx > 0) a.ldx = d->ldx;
   if (d->ldw > 0) a.ldw = d->ldw;
   if (d->ldy > 0) { a.ldy = d->ldy; a.ldr = d->ldy; }
-  if (d->Z > 1) { a.Z = d->Z; a.xz = d->xz; a.wz = d->wz; a.yz = d->yz; }
+  if (d->Z > 1) { a.Z = d->Z; a.xz = d->xz; a.wz = d->wz; a.yz = d->yz; a.bz = d->bz; }
   return gsv::launch_conv_gemm(dtype, a, (hipStream_t)stream);
+}
+
+int gsv_op_frame(const float* x, int n, int frame_len, int hop, int pad, int ld, int T_out, void* out, int dtype, gsv_stream_t stream) {
+  GSV_REQUIRE(x && out && n > 0 && frame_len > 0 && hop > 0 && ld >= frame_len && T_out > 0, "op_frame: bad argument");
+  GSV_REQUIRE(pad >= 0 && pad < n, "op_frame: reflect padding %d needs more than %d samples", pad, pad);
+  GSV_REQUIRE((long long)(T_out - 1) * hop + frame_len - pad <= (long long)n + pad, "op_frame: frames run past the (padded) signal");
+  GSV_REQUIRE(dtype == GSV_F16 || dtype == GSV_F32, "op_frame: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == GSV_F16) hipLaunchKernelGGL(gsv::frame_kernel<_Float16>, dim3(T_out), dim3(256), 0, s, x, n, frame_len, hop, pad, ld, T_out, (_Float16*)out);
+  else hipLaunchKernelGGL(gsv::frame_kernel<float>, dim3(T_out), dim3(256), 0, s, x, n, frame_len, hop, pad, ld, T_out, (float*)out);
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+int gsv_op_magnitude(const float* re_im, int T, int bins, float eps, float* spec, gsv_stream_t stream) {
+  GSV_REQUIRE(re_im && spec && T > 0 && bins > 0, "op_magnitude: bad argument");
+  hipLaunchKernelGGL(gsv::magnitude_kernel, dim3(gsv::cdiv(T, 32), gsv::cdiv(bins, 32)), dim3(256), 0, (hipStream_t)stream, re_im, T, bins, eps, spec);
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+int gsv_op_channel_norm(const void* x, int T, int C, const float* gamma, const float* beta, float eps, int act, float* scratch,
+                        void* y, int dtype, gsv_stream_t stream) {
+  GSV_REQUIRE(x && y && gamma && beta && scratch && T > 0 && C > 0, "op_channel_norm: bad argument");
+  GSV_REQUIRE(dtype == GSV_F16 || dtype == GSV_F32, "op_channel_norm: bad dtype");
+  const int slices = 64;                      // scratch: 64 * 2 * C floats
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(gsv::cdiv(C, 64), slices);
+  if (dtype == GSV_F16) {
+    hipLaunchKernelGGL(gsv::cnorm_stats_kernel<_Float16>, grid, dim3(64), 0, s, (const _Float16*)x, T, C, slices, scratch);
+    hipLaunchKernelGGL(gsv::cnorm_apply_kernel<_Float16>, grid, dim3(64), 0, s, (const _Float16*)x, T, C, slices, scratch, gamma, beta, eps, act, (_Float16*)y);
+  } else {
+    hipLaunchKernelGGL(gsv::cnorm_stats_kernel<float>, grid, dim3(64), 0, s, (const float*)x, T, C, slices, scratch);
+    hipLaunchKernelGGL(gsv::cnorm_apply_kernel<float>, grid, dim3(64), 0, s, (const float*)x, T, C, slices, scratch, gamma, beta, eps, act, (float*)y);
+  }
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
 }
 }

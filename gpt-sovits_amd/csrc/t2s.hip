@@ -1174,13 +1174,18 @@ int gsv_t2s_finalize(gsv_t2s_t* h) {
     }
     mega_pack_logits(h->staged["ar_predict_layer.weight"].data(), c.vocab, tmp.data());
     GSV_HIP(hipMemcpy(m.lpack, tmp.data(), gh * 2, hipMemcpyHostToDevice));
-    std::vector<MegaLayerP> lp(c.n_layer);
+    // fp32 parameters of a layer side by side (no pointer chasing inside the kernel)
+    GSV_RC(dev_alloc(h, (void**)&m.fpack, (size_t)c.n_layer * MEGA_FP_LAYER * 4));
     for (int i = 0; i < c.n_layer; ++i) {
       const LayerW& L = h->layers[i];
-      lp[i] = MegaLayerP{L.qkv_b, L.out_b, L.b1, L.b2, L.n1w, L.n1b, L.n2w, L.n2b};
+      float* dst = m.fpack + (size_t)i * MEGA_FP_LAYER;
+      const float* srcs[8] = {L.qkv_b, L.out_b, L.b1, L.b2, L.n1w, L.n1b, L.n2w, L.n2b};
+      const size_t ns[8] = {3 * d, d, ff, d, d, d, d, d};
+      for (int k = 0; k < 8; ++k) {
+        GSV_HIP(hipMemcpy(dst, srcs[k], ns[k] * 4, hipMemcpyDeviceToDevice));
+        dst += ns[k];
+      }
     }
-    GSV_RC(dev_alloc(h, (void**)&m.lp, lp.size() * sizeof(MegaLayerP)));
-    GSV_HIP(hipMemcpy(m.lp, lp.data(), lp.size() * sizeof(MegaLayerP), hipMemcpyHostToDevice));
     m.hop_bytes = mega_hop_bytes();
     GSV_RC(dev_alloc(h, (void**)&m.hop, m.hop_bytes));
     GSV_RC(dev_alloc(h, (void**)&m.err, 64));
@@ -1509,12 +1514,22 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
       GSV_HIP(hipMemsetAsync(m.err, 0, 64, s));
       MegaArgs a;
       memset(&a, 0, sizeof(a));
-      a.wpack = (const h8*)m.wpack; a.lpack = (const h8*)m.lpack; a.lp = m.lp;
+      a.wpack = (const h8*)m.wpack; a.lpack = (const h8*)m.lpack; a.fpack = m.fpack;
       a.kv = (_Float16*)h->kv; a.kv_layer_stride = h->kv_layer_stride; a.smax = h->max_seq;
       a.kv_len = h->d_kv_len; a.active = h->d_active; a.step_ctr = h->d_step; a.n_active = h->d_n_active;
       a.ytok = h->d_ytok; a.ycap = h->ycap; a.sp = h->d_sp; a.e_audio = h->e_audio; a.pe = h->pe; a.alpha_a = h->alpha_a;
       a.ybuf = h->ybuf; a.logits_out = h->logits; a.hop = m.hop; a.err = m.err; a.B = h->B; a.L = h->cfg.n_layer; a.V = h->cfg.vocab;
       a.nsteps = budget - 1; a.map_shared = map_local ? 0 : 1;
+      // measurement runs: GSV_MEGA_PROF=<file> dumps in-kernel shader-clock stamps of one (step, layer) for every wave
+      const char* prof_path = getenv("GSV_MEGA_PROF");
+      unsigned long long* d_prof = nullptr;
+      const size_t prof_n = (size_t)256 * 8 * 32;
+      if (prof_path && budget > 8) {
+        GSV_HIP(hipMalloc((void**)&d_prof, prof_n * 8));
+        GSV_HIP(hipMemsetAsync(d_prof, 0, prof_n * 8, s));
+        a.prof = d_prof; a.prof_step = getenv("GSV_MEGA_PROF_STEP") ? atoi(getenv("GSV_MEGA_PROF_STEP")) : 5;
+        a.prof_layer = getenv("GSV_MEGA_PROF_LAYER") ? atoi(getenv("GSV_MEGA_PROF_LAYER")) : 7;
+      }
       GSV_HIP(hipEventRecord(h->mega_ev[0], s));
       GSV_RC(launch_t2s_mega(a, s));
       GSV_HIP(hipEventRecord(h->mega_ev[1], s));
@@ -1527,6 +1542,24 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
         return GSV_ERR_STATE;
       }
       (void)hipEventElapsedTime(&h->last_decode_ms, h->mega_ev[0], h->mega_ev[1]);
+      if (d_prof) {
+        std::vector<unsigned long long> hp(prof_n);
+        GSV_HIP(hipMemcpy(hp.data(), d_prof, prof_n * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(d_prof);
+        if (FILE* f = fopen(prof_path, "w")) {
+          fprintf(f, "# decode %.3f ms for %d steps; stamps of step %d layer %d: wg wave stamp0 then deltas to stamp0\n",
+                  h->last_decode_ms, budget - 1, a.prof_step, a.prof_layer);
+          for (int wg = 0; wg < 256; ++wg)
+            for (int w = 0; w < 8; ++w) {
+              const unsigned long long* p = &hp[((size_t)wg * 8 + w) * 32];
+              if (!p[0]) continue;
+              fprintf(f, "%d %d %llu", wg, w, p[0]);
+              for (int i = 1; i < 24; ++i) fprintf(f, " %lld", p[i] ? (long long)(p[i] - p[0]) : -1ll);
+              fprintf(f, "\n");
+            }
+          fclose(f);
+        }
+      }
       // every row ends by the budget's last step (early == step >= max_steps - 1); row 0's step counter tells how
       // far the longest-running group got only for its own group, so report the budget like the launch loop does
       h->last_decode_mode = 1; h->last_decode_steps = budget - 1;

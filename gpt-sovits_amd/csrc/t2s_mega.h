@@ -9,14 +9,10 @@
 
 namespace gsv {
 
-struct MegaLayerP {       // per-layer fp32 parameter pointers (device memory)
-  const float *qkv_b, *out_b, *b1, *b2, *n1w, *n1b, *n2w, *n2b;
-};
-
 struct MegaState {        // owned by the t2s handle
   void* wpack = nullptr;          // packed fp16 weights  [layer][member][wave][60 KiB-instructions][64 lanes][8 halfs]
   void* lpack = nullptr;          // packed logits weights [member][wave][12][64][8]
-  MegaLayerP* lp = nullptr;       // [n_layer]
+  float* fpack = nullptr;         // [n_layer][6656] fp32: qkv_b | out_b | b1 | b2 | n1w | n1b | n2w | n2b
   unsigned long long* hop = nullptr;   // hop granule buffers, all groups
   size_t hop_bytes = 0;
   unsigned* err = nullptr;        // [4]: timeout word, epoch, block, code
@@ -26,7 +22,7 @@ struct MegaState {        // owned by the t2s handle
 };
 
 struct MegaArgs {
-  const h8* wpack; const h8* lpack; const MegaLayerP* lp;
+  const h8* wpack; const h8* lpack; const float* fpack;
   _Float16* kv; unsigned long long kv_layer_stride; int smax;     // KV arena [layer][k|v][row][head][pos][32]
   int *kv_len, *active, *step_ctr, *n_active, *ytok; int ycap;
   const StepParams* sp;
@@ -35,6 +31,8 @@ struct MegaArgs {
   float* logits_out;              // [B][V] fp32: each row's logits of its last sampled step (test hook gsv_t2s_debug_logits)
   unsigned long long* hop; unsigned* err;
   int B, L, V, nsteps;
+  unsigned long long* prof;       // optional [256 workgroups][8 waves][32] s_memtime stamps of one (step, layer); null = off
+  int prof_step, prof_layer;
   int map_shared;                 // 1: workgroups reading the same weight slice share an XCD (default), 0: group = XCD
 };
 
@@ -48,6 +46,7 @@ void mega_pack_logits(const float* pred_w, int V, _Float16* dst);
 size_t mega_layer_pack_halfs();
 size_t mega_logits_pack_halfs();
 size_t mega_hop_bytes();
+constexpr int MEGA_FP_LAYER = 6656;      // floats per layer in fpack
 
 int mega_census(hipStream_t s, unsigned* d_scratch, unsigned* h_pinned);   // 1 ok, 0 not co-resident, <0 error
 int launch_t2s_mega(const MegaArgs& a, hipStream_t s);

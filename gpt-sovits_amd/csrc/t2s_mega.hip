@@ -79,13 +79,14 @@ constexpr int L_AT = L_XS + RMAX * XS_LD * 2;                 // half [RMAX][XS_
 constexpr int L_HS = L_AT + RMAX * XS_LD * 2;                 // half [RMAX][HS_LD] FFN hidden
 constexpr int L_RED = L_HS + RMAX * HS_LD * 2;                // f4 [24][64] split-K partials
 constexpr int L_QKV = L_RED + 24 * 64 * 16;                   // half [2][3][32] q,k,v of the own rows
-constexpr int L_ATT = L_QKV + 2 * 3 * 32 * 2;                 // float [4] m + [4][36] acc,l
-constexpr int L_ST = L_ATT + 16 + 4 * 36 * 4;                 // int: active[RMAX], kvlen[RMAX], step[RMAX], abort, any_active
+constexpr int L_ATT = L_QKV + 2 * 3 * 32 * 2;                 // float [8] m + [8][36] acc,l (8 attention waves)
+constexpr int L_STAGE = L_ATT + 32 + 8 * 36 * 4;              // 4 x 1 KB: per-wave transposition buffers of the publishers
+constexpr int L_ST = L_STAGE + 4 * 1024;                      // int: active[RMAX], kvlen[RMAX], step[RMAX], abort, any_active
 constexpr int L_SEEN = L_ST + 64;                             // bytes [VPAD]
 constexpr int L_KV = (L_SEEN + VPAD + 63) & ~63;              // [2 rows][K|V][KV_CAP][64 B]
 constexpr int L_TOTAL = L_KV + 2 * 2 * KV_CAP * 64;
 static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
-static_assert(L_XS % 16 == 0 && L_AT % 16 == 0 && L_HS % 16 == 0 && L_RED % 16 == 0 && L_QKV % 16 == 0 && L_KV % 16 == 0, "LDS alignment");
+static_assert(L_STAGE % 16 == 0 && L_XS % 16 == 0 && L_AT % 16 == 0 && L_HS % 16 == 0 && L_RED % 16 == 0 && L_QKV % 16 == 0 && L_KV % 16 == 0, "LDS alignment");
 
 __device__ __forceinline__ void gstore(gu64* p, unsigned tag, unsigned val) {
   __hip_atomic_store(p, ((u64)tag << 32) | val, RLX_AGENT);           // global_store_dwordx2 ... sc1 (one untorn granule)
@@ -105,6 +106,10 @@ __device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// fp32 parameters of one layer in the packed buffer (MegaArgs::fpack): offsets in floats
+constexpr int FP_QKVB = 0, FP_OUTB = 1536, FP_B1 = 2048, FP_B2 = 4096, FP_N1W = 4608, FP_N1B = 5120, FP_N2W = 5632, FP_N2B = 6144,
+              FP_LAYER = 6656;
+
 struct Ctx {
   unsigned char* smem;
   int lane, wave, cw, tid_c;
@@ -112,13 +117,34 @@ struct Ctx {
   int group, member, head, half, R;
   gu64* hop;
   gu32* err;
+  unsigned long long* prof;     // this wave's 32 stamp slots or null
+  bool prof_on;
 };
 
-__device__ __forceinline__ int* st_active(const Ctx& c) { return (int*)(c.smem + L_ST); }
-__device__ __forceinline__ int* st_kvlen(const Ctx& c) { return (int*)(c.smem + L_ST) + RMAX; }
-__device__ __forceinline__ int* st_step(const Ctx& c) { return (int*)(c.smem + L_ST) + 2 * RMAX; }
-__device__ __forceinline__ volatile int* st_abort(const Ctx& c) { return (volatile int*)(c.smem + L_ST) + 3 * RMAX; }
-__device__ __forceinline__ volatile int* st_any(const Ctx& c) { return (volatile int*)(c.smem + L_ST) + 3 * RMAX + 1; }
+// in-kernel stamp (measurement runs: GSV_MEGA_PROF=<file>): 100 MHz real-time counter at point i of the profiled layer
+#define MG_STAMP(q, i) do { if ((q).prof_on && (q).lane == 0) (q).prof[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
+// The row state lives in LDS and is addressed through LDS-typed pointers: through a generic pointer the volatile abort flag
+// became a FLAT load, and a flat load is waited for with vmcnt(0) -- which drained the whole weight prefetch after every
+// barrier (seen in the ISA; the dynamic LDS segment starts at LDS address 0: there is no static LDS in this kernel).
+typedef __attribute__((address_space(3))) int lds_int;
+typedef volatile __attribute__((address_space(3))) int lds_vint;
+__device__ __forceinline__ lds_int* st_active(const Ctx&) { return (lds_int*)(unsigned)L_ST; }
+__device__ __forceinline__ lds_int* st_kvlen(const Ctx&) { return (lds_int*)(unsigned)L_ST + RMAX; }
+__device__ __forceinline__ lds_int* st_step(const Ctx&) { return (lds_int*)(unsigned)L_ST + 2 * RMAX; }
+__device__ __forceinline__ lds_vint* st_abort(const Ctx&) { return (lds_vint*)(unsigned)L_ST + 3 * RMAX; }
+__device__ __forceinline__ lds_int* st_cbar(const Ctx&) { return (lds_int*)(unsigned)L_ST + 3 * RMAX + 2; }
+
+// Barrier among the 4 compute waves only (an s_barrier would also wait for the comm waves, which are busy issuing the next
+// layer's K/V loads during P1): an arrival counter in LDS; LDS operations of a wave complete in order, so the add is behind
+// the wave's earlier LDS writes.  `gen` counts arrivals expected so far (same in every compute wave).
+__device__ __forceinline__ void compute_barrier(const Ctx& q, int& gen) {
+  gen += 4;
+  if (q.lane == 0) __hip_atomic_fetch_add(st_cbar(q), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  unsigned spins = 0;
+  while (*(lds_vint*)st_cbar(q) < gen && !*st_abort(q) && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(0);
+  asm volatile("" ::: "memory");
+}
 
 __device__ __noinline__ void mega_fail(const Ctx& c, unsigned epoch, unsigned code) {
   *st_abort(c) = 1;
@@ -130,20 +156,50 @@ __device__ __noinline__ void mega_fail(const Ctx& c, unsigned epoch, unsigned co
   }
 }
 
-// one wave re-reads its N granules per lane (granule k*64 + lane of `g`) until every tag equals `epoch`
+// one wave re-reads N granules per lane (granule k*64 + lane) of ONE or TWO rows (g1 may be null) until every tag equals `epoch`
 template <int N>
-__device__ __forceinline__ bool sweep(const Ctx& c, gu64* g, int nvalid, unsigned epoch, unsigned (&v)[N], unsigned code) {
+__device__ __forceinline__ bool sweep2(const Ctx& c, gu64* g0, gu64* g1, int nvalid, unsigned epoch, unsigned (&v0)[N],
+                                       unsigned (&v1)[N], unsigned code) {
+  // Every producer writes whole 128-B lines (16 granules) with one store instruction, so the LAST granule of each line is
+  // polled first: one load per lane and row covers 64 lines, a 16th of a full pass.  When most lines are there the rows are
+  // read in full -- and still checked tag by tag (the hint is an optimisation: the data remains its own flag).  Full-row
+  // polling by 4 waves x 256 CUs was ~8 TB/s of fabric traffic by itself.
+  {
+    const int nlines = (nvalid + 15) >> 4;
+    for (unsigned spins = 0;; ++spins) {
+      int miss = 0;
+      for (int l0 = 0; l0 < nlines; l0 += 64) {
+        const int ln = l0 + c.lane;
+        if (ln < nlines) {
+          const int i = min(ln * 16 + 15, nvalid - 1);
+          miss += (unsigned)(gload(g0 + i) >> 32) != epoch;
+          if (g1) miss += (unsigned)(gload(g1 + i) >> 32) != epoch;
+        }
+      }
+      // most lines there: the stragglers are at most one poll away, go on with full passes (one round trip fewer at the end)
+      if (__popcll(__ballot(miss != 0)) * 4 <= nlines) break;
+      if (spins > SPIN_MAX || *st_abort(c) || (spins & 1023u) == 1023u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
+        mega_fail(c, epoch, code | 0x100u);
+        return false;
+      }
+      if (spins < 8) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
+    }
+  }
   for (unsigned spins = 0;; ++spins) {
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const int i = k * 64 + c.lane;
+      v0[k] = 0u; v1[k] = 0u;
       if (i < nvalid) {
-        const u64 x = gload(g + i);
-        v[k] = (unsigned)x;
+        const u64 x = gload(g0 + i);
+        v0[k] = (unsigned)x;
         ok &= (unsigned)(x >> 32) == epoch;
-      } else {
-        v[k] = 0u;
+        if (g1) {
+          const u64 y = gload(g1 + i);
+          v1[k] = (unsigned)y;
+          ok &= (unsigned)(y >> 32) == epoch;
+        }
       }
     }
     if (__all(ok)) return true;
@@ -153,6 +209,12 @@ __device__ __forceinline__ bool sweep(const Ctx& c, gu64* g, int nvalid, unsigne
     }
     __builtin_amdgcn_s_sleep(2);
   }
+}
+
+template <int N>
+__device__ __forceinline__ bool sweep(const Ctx& c, gu64* g, int nvalid, unsigned epoch, unsigned (&v)[N], unsigned code) {
+  unsigned dummy[N];
+  return sweep2<N>(c, g, nullptr, nvalid, epoch, v, dummy, code);
 }
 
 // LayerNorm of one row held as 8 values per lane (element k*64 + lane); gamma == null: identity (layer 0's embedding)
@@ -228,40 +290,185 @@ __device__ __forceinline__ bool group_done(const Ctx& c) {
   return !any;
 }
 
+// Attention of the member's own rows (H4: softmax(q K^T / sqrt(32)) V over the cached keys + this step's key): row ro is
+// served by NW waves, its keys dealt to them in 16-key groups, 4 lanes per key (8 dims each).  Two passes over the
+// LDS image (scores -> lane maximum -> weights), so there is no per-key rescaling; v_dot2_f32_f16 for q . k.
+template <int NW>     // waves per row; aw = ro * NW + hq
+__device__ __forceinline__ void attention_part(const MegaArgs& a, const Ctx& q, int l, int aw) {
+  unsigned char* smem = q.smem;
+  const int ro = aw / NW, hq = aw % NW, r = 2 * ro + q.half;
+  const bool rv = r < q.R && st_active(q)[r];
+  const int n_old = rv ? st_kvlen(q)[r] : 0;
+  const int part = q.lane & 3, slot = q.lane >> 2;
+  const float scale = 0.17677669529663687f;            // 1 / sqrt(32)
+  const _Float16* qkv_s = (const _Float16*)(smem + L_QKV) + ro * 3 * HD;
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  const h8 qv = *(const h8*)(qkv_s + part * 8);
+  auto score = [&](const h8& kk) {
+    float sc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      sc = __builtin_amdgcn_fdot2((h2v){qv[2 * i], qv[2 * i + 1]}, (h2v){kk[2 * i], kk[2 * i + 1]}, sc, false);
+    sc += __shfl_xor(sc, 1, 64);
+    sc += __shfl_xor(sc, 2, 64);
+    return sc * scale;
+  };
+  const unsigned char* kimg = smem + L_KV + (ro * 2 + 0) * KV_CAP * 64;
+  const unsigned char* vimg = smem + L_KV + (ro * 2 + 1) * KV_CAP * 64;
+  const int n_img = min(n_old, KV_CAP);
+  constexpr int NT = KV_CAP / (16 * NW);               // image keys per lane
+  float sc[NT + 1];
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = (NW * t + hq) * 16 + slot;
+    const h8 kk = *(const h8*)(kimg + min(j, KV_CAP - 1) * 64 + part * 16);
+    const float v = score(kk);
+    sc[t] = j < n_img ? v : -INFINITY;
+    m = fmaxf(m, sc[t]);
+  }
+  {                                                    // this step's own key: wave hq == 0, key slot 0
+    const h8 kk = *(const h8*)(qkv_s + HD + part * 8);
+    const float v = score(kk);
+    sc[NT] = (rv && hq == 0 && slot == 0) ? v : -INFINITY;
+    m = fmaxf(m, sc[NT]);
+  }
+  float lsum = 0.f, acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int t = 0; t <= NT; ++t) {
+    const int j = (NW * t + hq) * 16 + slot;
+    const h8 vv = t < NT ? *(const h8*)(vimg + min(j, KV_CAP - 1) * 64 + part * 16) : *(const h8*)(qkv_s + 2 * HD + part * 8);
+    if (sc[t] != -INFINITY) {                          // masked keys may hold anything (unwritten image tail): never 0 * NaN
+      const float p = __expf(sc[t] - m);
+      lsum += p;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += p * (float)vv[i];
+    }
+  }
+  if (n_old > KV_CAP) {                                // long rows: the tail comes straight from HBM (online update)
+    const _Float16* kvb = a.kv + ((size_t)(q.group + MG_GROUPS * r) * NH + q.head) * (size_t)a.smax * HD + part * 8;
+    const _Float16* kg_ = kvb + (size_t)(l * 2 + 0) * a.kv_layer_stride;
+    const _Float16* vg_ = kvb + (size_t)(l * 2 + 1) * a.kv_layer_stride;
+    for (int j0 = KV_CAP + hq * 16; j0 < n_old; j0 += 16 * NW) {
+      const int j = j0 + slot, jc = min(j, n_old - 1);
+      const h8 kk = __builtin_nontemporal_load((const h8*)(kg_ + (size_t)jc * HD));
+      const h8 vv = __builtin_nontemporal_load((const h8*)(vg_ + (size_t)jc * HD));
+      const float v = score(kk);
+      if (j < n_old) {
+        const float mn = fmaxf(m, v);
+        const float corr = m == -INFINITY ? 0.f : __expf(m - mn), p = __expf(v - mn);
+        lsum = lsum * corr + p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = acc[i] * corr + p * (float)vv[i];
+        m = mn;
+      }
+    }
+  }
+  const float wm = wave_max(m);
+  const float f = (m == -INFINITY) ? 0.f : __expf(m - wm);
+  lsum *= f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] *= f;
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) {
+    lsum += __shfl_xor(lsum, o, 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+  }
+  float* s_m = (float*)(smem + L_ATT);
+  float* s_acc = s_m + 8;
+  if (q.lane < 4) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_acc[aw * 36 + q.lane * 8 + i] = acc[i];
+    if (q.lane == 0) { s_acc[aw * 36 + 32] = lsum; s_m[aw] = wm; }
+  }
+}
+
+// K/V image staging by the comm waves: the cached K and V of the member's own rows for the NEXT layer go global -> registers
+// (non-temporal 16-B lane loads = 1 KiB per wave instruction) and registers -> LDS after the current layer's attention has
+// released the image.  A CU's vector-memory pipeline returns data in issue order ACROSS waves, so while long HBM loads are
+// outstanding every poll of a hop waits behind them (measured: +2 us per hop with the loads in dedicated waves a layer ahead,
+// 2.6 us of blocked issue per third of the image as LDS-DMA of the compute waves).  Therefore the loads are issued at B1 of
+// P1 -- the start of the only poll-free stretch of a layer (QKV GEMM, reduce, attention: ~3 us; hop B cannot complete before
+// the attention has finished anyway) -- by the comm waves, which have nothing else to do there and skip P1's inner barriers.
+// KiB slot t of wave cw: row t / 10, K|V (t / 5) & 1, KiB 4 (t % 5) + cw.
+constexpr int KV_T = KV_CAP / 16;            // KiB-instructions per (row, K|V) image = slots per wave (20)
+struct KvStage { h8 r[KV_T]; };
+
+__device__ __forceinline__ void kv_stage_load(const MegaArgs& a, const Ctx& q, int layer, int extra, KvStage& st) {
+#pragma unroll
+  for (int t = 0; t < KV_T; ++t) {
+    const int ro = t / (KV_T / 2), which = (t / (KV_T / 4)) & 1, i = 4 * (t % (KV_T / 4)) + q.cw;
+    const int r = 2 * ro + q.half;
+    if (r < q.R && st_active(q)[r]) {
+      const int nki = (min(st_kvlen(q)[r] + extra, KV_CAP) + 15) >> 4;
+      if (i < nki) {
+        // the arena is allocated to smax positions per (row, head): a partly valid KiB reads allocated memory
+        const _Float16* src = a.kv + (size_t)(layer * 2 + which) * a.kv_layer_stride +
+                              ((size_t)(q.group + MG_GROUPS * r) * NH + q.head) * (size_t)a.smax * HD;
+        st.r[t] = __builtin_nontemporal_load((const h8*)(src + (size_t)i * 16 * HD) + q.lane);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void kv_stage_store(const Ctx& q, int extra, const KvStage& st) {
+#pragma unroll
+  for (int t = 0; t < KV_T; ++t) {
+    const int ro = t / (KV_T / 2), which = (t / (KV_T / 4)) & 1, i = 4 * (t % (KV_T / 4)) + q.cw;
+    const int r = 2 * ro + q.half;
+    if (r < q.R && st_active(q)[r]) {
+      const int nki = (min(st_kvlen(q)[r] + extra, KV_CAP) + 15) >> 4;
+      if (i < nki) *((h8*)(q.smem + L_KV + (ro * 2 + which) * KV_CAP * 64 + i * 1024) + q.lane) = st.r[t];
+    }
+  }
+}
+
 __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, const StepParams& sp) {
   Ctx q = c0;
   unsigned char* smem = c0.smem;
   const int R = c0.R;
   const int V = a.V, EOS = a.V - 1;
-  const bool sampler = c0.member < R && c0.cw == 0;      // wave 0 of member r samples local row r
+  constexpr bool sweeper = true;                     // every comm wave sweeps one row (row cw) and stages a quarter of the K/V
+  const bool sampler = c0.member < R && c0.cw == 0;  // wave 0 of member r samples local row r
   const int EPS = 4 * a.L + 2;                       // hops per step
   unsigned char* seen = smem + L_SEEN;
+  KvStage kvs;
+  kv_stage_load(a, q, 0, 0, kvs);
+  kv_stage_store(q, 0, kvs);                         // layer 0's image (the attention waves read it after B1 + two compute barriers)
   for (int s = 0; s < a.nsteps; ++s) {
     const unsigned ep0 = (unsigned)s * (unsigned)EPS;  // epoch of hop i of this step = ep0 + i + 1
     for (int l = 0; l < a.L; ++l) {
-      const MegaLayerP lp = a.lp[l];
+      const float* lp = a.fpack + (size_t)l * FP_LAYER;
       relaunder(q);
+      q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer;
+      MG_STAMP(q, 0);
+      const int ra = q.cw;                             // this wave's row
       // ---- hop A: y of the previous layer (or the step's input embedding) -> LayerNorm -> XS / XRES
-      {
+      if (sweeper) {
         const unsigned ep = ep0 + 4 * l + 1;
-        if (q.cw < R) {
-          unsigned v[8];
+        if (ra < R) {
+          unsigned va[8];
           float gm[8], bt[8];
-          const float* gp = l > 0 ? a.lp[l - 1].n2w : nullptr;
-          const float* bp = l > 0 ? a.lp[l - 1].n2b : nullptr;
+          const float* gp = l > 0 ? lp - FP_LAYER + FP_N2W : nullptr;
+          const float* bp = l > 0 ? lp - FP_LAYER + FP_N2B : nullptr;
           if (gp) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) { gm[k] = gp[k * 64 + q.lane]; bt[k] = bp[k * 64 + q.lane]; }
           }
           bool ok = true;
           if (s == 0 && l == 0) {
-            const float* yb = a.ybuf + (size_t)(q.group + MG_GROUPS * q.cw) * D;
+            const float* ya = a.ybuf + (size_t)(q.group + MG_GROUPS * ra) * D;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = __float_as_uint(yb[k * 64 + q.lane]);
+            for (int k = 0; k < 8; ++k) va[k] = __float_as_uint(ya[k * 64 + q.lane]);
           } else {
-            ok = sweep<8>(q, q.hop + HOP_A + q.cw * 512, 512, ep, v, 1u);
+            ok = sweep<8>(q, q.hop + HOP_A + ra * 512, 512, ep, va, 1u);
           }
-          if (ok) ln_row(q, q.cw, v, gp ? gm : nullptr, bt);
+          if (ok) {
+            ln_row(q, ra, va, gp ? gm : nullptr, bt);
+          }
         }
         if (l == 0 && s > 0 && q.cw == 0) {
           // row state published by the samplers with the embedding: {active} per row
@@ -273,61 +480,87 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
           }
         }
       }
+      MG_STAMP(q, 1);
       MG_BAR();                                                          // B1
       if (*st_abort(q)) return;
       if (l == 0 && s > 0 && group_done(q)) return;                      // every row of the group has finished
-      MG_BAR();                                                          // B2
-      MG_BAR();                                                          // B3
-      MG_BAR();                                                          // B4
+      MG_STAMP(q, 2);
+      // next layer's K/V (across the step boundary the rows hold one more position: appended at this step's layer 0);
+      // the compute waves run the QKV GEMM, the reduce and the attention meanwhile, synchronised among themselves
+      const int kv_nl = l + 1 < a.L ? l + 1 : 0, kv_extra = l + 1 < a.L ? 0 : 1;
+      const bool kv_more = l + 1 < a.L || s + 1 < a.nsteps;
+      if (kv_more) kv_stage_load(a, q, kv_nl, kv_extra, kvs);
+      MG_STAMP(q, 4);
+      MG_BAR();                                                          // B4: the attention is done, the K/V image is free
+      MG_STAMP(q, 5);
       relaunder(q);
+      if (kv_more) kv_stage_store(q, kv_extra, kvs);
       // ---- hop B: attention output of all heads -> AT
-      if (q.cw < R) {
-        unsigned v[4];
-        if (sweep<4>(q, q.hop + HOP_B + q.cw * 256, 256, ep0 + 4 * l + 2, v, 3u)) {
-          unsigned* at = (unsigned*)(smem + L_AT) + q.cw * (XS_LD / 2);
+      if (sweeper && ra < R) {
+        unsigned va[4];
+        if (sweep<4>(q, q.hop + HOP_B + ra * 256, 256, ep0 + 4 * l + 2, va, 3u)) {
+          unsigned* at = (unsigned*)(smem + L_AT);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) at[k * 64 + q.lane] = v[k];
+          for (int k = 0; k < 4; ++k) {
+            at[ra * (XS_LD / 2) + k * 64 + q.lane] = va[k];
+          }
         }
       }
+      MG_STAMP(q, 6);
       MG_BAR();                                                          // B1
       if (*st_abort(q)) return;
+      MG_STAMP(q, 7);
       MG_BAR();                                                          // B2
+      MG_STAMP(q, 8);
       relaunder(q);
       // ---- hop C: y1 -> LayerNorm1 -> XS / XRES
-      if (q.cw < R) {
-        unsigned v[8];
+      if (sweeper && ra < R) {
+        unsigned va[8];
         float gm[8], bt[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { gm[k] = lp.n1w[k * 64 + q.lane]; bt[k] = lp.n1b[k * 64 + q.lane]; }
-        if (sweep<8>(q, q.hop + HOP_C + q.cw * 512, 512, ep0 + 4 * l + 3, v, 4u)) ln_row(q, q.cw, v, gm, bt);
-      }
-      MG_BAR();                                                          // B1
-      if (*st_abort(q)) return;
-      MG_BAR();                                                          // B2
-      relaunder(q);
-      // ---- hop D: h -> HS
-      if (q.cw < R) {
-        unsigned v[16];
-        if (sweep<16>(q, q.hop + HOP_D + q.cw * 1024, 1024, ep0 + 4 * l + 4, v, 5u)) {
-          unsigned* hs = (unsigned*)(smem + L_HS) + q.cw * (HS_LD / 2);
-#pragma unroll
-          for (int k = 0; k < 16; ++k) hs[k * 64 + q.lane] = v[k];
+        for (int k = 0; k < 8; ++k) { gm[k] = lp[FP_N1W + k * 64 + q.lane]; bt[k] = lp[FP_N1B + k * 64 + q.lane]; }
+        if (sweep<8>(q, q.hop + HOP_C + ra * 512, 512, ep0 + 4 * l + 3, va, 4u)) {
+          ln_row(q, ra, va, gm, bt);
         }
       }
+      MG_STAMP(q, 9);
       MG_BAR();                                                          // B1
       if (*st_abort(q)) return;
+      MG_STAMP(q, 10);
       MG_BAR();                                                          // B2
+      MG_STAMP(q, 11);
+      relaunder(q);
+      // ---- hop D: h -> HS
+      if (sweeper && ra < R) {
+        unsigned va[16];
+        if (sweep<16>(q, q.hop + HOP_D + ra * 1024, 1024, ep0 + 4 * l + 4, va, 5u)) {
+          unsigned* hs = (unsigned*)(smem + L_HS);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            hs[ra * (HS_LD / 2) + k * 64 + q.lane] = va[k];
+          }
+        }
+      }
+      MG_STAMP(q, 12);
+      MG_BAR();                                                          // B1
+      if (*st_abort(q)) return;
+      MG_STAMP(q, 13);
+      MG_BAR();                                                          // B2
+      MG_STAMP(q, 14);
     }
     relaunder(q);
     // ---- tail: hop A' -> LayerNorm2 of the last layer -> XS; then the samplers
-    const MegaLayerP lpl = a.lp[a.L - 1];
+    const float* lpl = a.fpack + (size_t)(a.L - 1) * FP_LAYER;
     const unsigned epA = ep0 + 4 * a.L + 1, epE = ep0 + 4 * a.L + 2;
-    if (q.cw < R) {
-      unsigned v[8];
+    if (sweeper && q.cw < R) {
+      const int ra = q.cw;
+      unsigned va[8];
       float gm[8], bt[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { gm[k] = lpl.n2w[k * 64 + q.lane]; bt[k] = lpl.n2b[k * 64 + q.lane]; }
-      if (sweep<8>(q, q.hop + HOP_A + q.cw * 512, 512, epA, v, 6u)) ln_row(q, q.cw, v, gm, bt);
+      for (int k = 0; k < 8; ++k) { gm[k] = lpl[FP_N2W + k * 64 + q.lane]; bt[k] = lpl[FP_N2B + k * 64 + q.lane]; }
+      if (sweep<8>(q, q.hop + HOP_A + ra * 512, 512, epA, va, 6u)) {
+        ln_row(q, ra, va, gm, bt);
+      }
     }
     MG_BAR();                                                            // B1
     if (*st_abort(q)) return;
@@ -341,49 +574,48 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
       float x0[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) x0[k] = 0.f;
-      bool ok = true;
-      if (was_active) {
+      // The logits row is consumed even when the row has finished: its arrival proves that every member has read this
+      // step's HOP_A (the last layer's y2) -- only then may the next step's embedding overwrite that buffer.
+      unsigned lv[17];
+      const bool ok = sweep<17>(q, q.hop + HOP_E + r * VPAD, V, epE, lv, 7u);
+      if (was_active && ok) {
         const int step = st_step(q)[r];
-        unsigned lv[17];
-        ok = sweep<17>(q, q.hop + HOP_E + r * VPAD, V, epE, lv, 7u);
-        if (ok) {
-          const int Veff = step < sp.eos_mask_steps ? V - 1 : V;
-          float x[17];
+        const int Veff = step < sp.eos_mask_steps ? V - 1 : V;
+        float x[17];
 #pragma unroll
-          for (int i = 0; i < 17; ++i) {
-            const int v = q.lane + 64 * i;
-            if (v < V) a.logits_out[(size_t)b * V + v] = __uint_as_float(lv[i]);
-            x[i] = v < Veff ? __uint_as_float(lv[i]) : -INFINITY;
-            if (sp.rep_penalty != 1.0f && v < Veff && seen[v]) x[i] = x[i] < 0.f ? x[i] * sp.rep_penalty : x[i] / sp.rep_penalty;
+        for (int i = 0; i < 17; ++i) {
+          const int v = q.lane + 64 * i;
+          if (v < V) a.logits_out[(size_t)b * V + v] = __uint_as_float(lv[i]);
+          x[i] = v < Veff ? __uint_as_float(lv[i]) : -INFINITY;
+          if (sp.rep_penalty != 1.0f && v < Veff && seen[v]) x[i] = x[i] < 0.f ? x[i] * sp.rep_penalty : x[i] / sp.rep_penalty;
+        }
+        const float* nrow = nullptr;
+        if (sp.noise) nrow = sp.noise + ((size_t)step * sp.noise_rows + (sp.noise_rows > 1 ? b : 0)) * V;
+        int smp, amx;
+        sample_core<17>(x, Veff, sp.top_k, sp.top_p, sp.temperature, nrow, sp.seed, b, step, &smp, &amx);
+        const bool fin = smp == EOS || amx == EOS;
+        const bool early = (sp.early_stop_num != -1 && (step + 1) > sp.early_stop_num) || step >= sp.max_steps - 1;
+        const int prev_len = sp.P + step;
+        if (q.lane == 0) {
+          if (prev_len < a.ycap) a.ytok[(size_t)b * a.ycap + prev_len] = smp;
+          if (smp >= 0 && smp < VPAD) seen[smp] = 1;
+          if (fin || early) {
+            a.active[b] = 0;
+            sp.out_len[b] = step;
+            atomicSub(a.n_active, 1);
+          } else {
+            sp.out_tokens[(size_t)b * sp.max_steps + step] = smp;
+            a.kv_len[b] = st_kvlen(q)[r] + 1;
           }
-          const float* nrow = nullptr;
-          if (sp.noise) nrow = sp.noise + ((size_t)step * sp.noise_rows + (sp.noise_rows > 1 ? b : 0)) * V;
-          int smp, amx;
-          sample_core<17>(x, Veff, sp.top_k, sp.top_p, sp.temperature, nrow, sp.seed, b, step, &smp, &amx);
-          const bool fin = smp == EOS || amx == EOS;
-          const bool early = (sp.early_stop_num != -1 && (step + 1) > sp.early_stop_num) || step >= sp.max_steps - 1;
-          const int prev_len = sp.P + step;
-          if (q.lane == 0) {
-            if (prev_len < a.ycap) a.ytok[(size_t)b * a.ycap + prev_len] = smp;
-            if (smp >= 0 && smp < VPAD) seen[smp] = 1;
-            if (fin || early) {
-              a.active[b] = 0;
-              sp.out_len[b] = step;
-              atomicSub(a.n_active, 1);
-            } else {
-              sp.out_tokens[(size_t)b * sp.max_steps + step] = smp;
-              a.kv_len[b] = st_kvlen(q)[r] + 1;
-            }
-            a.step_ctr[b] = step + 1;
-          }
-          if (!(fin || early)) {
-            now_active = 1;
-            const int tok = min(max(smp, 0), V - 1);
-            const float* e = a.e_audio + (size_t)tok * D;
-            const float* p = a.pe + (size_t)(sp.P + step) * D;
+          a.step_ctr[b] = step + 1;
+        }
+        if (!(fin || early)) {
+          now_active = 1;
+          const int tok = min(max(smp, 0), V - 1);
+          const float* e = a.e_audio + (size_t)tok * D;
+          const float* p = a.pe + (size_t)(sp.P + step) * D;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) x0[k] = e[k * 64 + q.lane] + a.alpha_a * p[k * 64 + q.lane];
-          }
+          for (int k = 0; k < 8; ++k) x0[k] = e[k * 64 + q.lane] + a.alpha_a * p[k * 64 + q.lane];
         }
       }
       if (ok && s + 1 < a.nsteps) {
@@ -401,33 +633,10 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
   const int R = c0.R;
   const int V = a.V;
   const int EPS = 4 * a.L + 2;
-  const float scale = rsqrtf((float)HD);
   // own rows of this member (attention): local rows 2*ro + half, ro = 0, 1
   auto kv_row_base = [&](int layer, int which, int r) -> const _Float16* {
     const int b = q.group + MG_GROUPS * r;
     return a.kv + ((size_t)(layer * 2 + which)) * a.kv_layer_stride + ((size_t)b * NH + q.head) * (size_t)a.smax * HD;
-  };
-  // K/V image of `layer`: st_kvlen + extra cached positions per own row, LDS-DMA, dealt round-robin to the 4 compute waves
-  auto kv_prefetch = [&](int layer, int extra) {
-    int item = 0;
-#pragma unroll
-    for (int ro = 0; ro < 2; ++ro) {
-      const int r = 2 * ro + q.half;
-      if (r >= R || !st_active(q)[r]) continue;
-      const int n = min(st_kvlen(q)[r] + extra, KV_CAP);
-      const int nki = (n + 15) >> 4;
-#pragma unroll
-      for (int which = 0; which < 2; ++which) {
-        const _Float16* src = kv_row_base(layer, which, r);
-        const unsigned dst0 = (unsigned)(L_KV + (ro * 2 + which) * KV_CAP * 64);
-        for (int i = 0; i < nki; ++i, ++item) {
-          if ((item & 3) != q.cw) continue;
-          // the arena is allocated to smax positions per (row, head): a partly valid KiB reads allocated memory
-          const int pos = min(16 * i + (q.lane >> 2), a.smax - 1);
-          glds16_nt(src + (size_t)pos * HD + (q.lane & 3) * 8, __builtin_amdgcn_readfirstlane(dst0 + (unsigned)i * 1024u));
-        }
-      }
-    }
   };
   const h8* wp = a.wpack;
   auto p1_src = [&](int layer) { return wp + ((size_t)layer * LAYER_HALFS + ((size_t)q.head * 4 + q.cw) * WI_P1 * 512) / 8 + q.lane; };
@@ -437,29 +646,38 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
   // P1's slice is held as two halves (tiles q0 q1 k0 | k1 v0 v1): the second half is requested one phase later than the
   // first, so that FFN2's slice + the whole next P1 slice are never live together (160 + operands would spill)
   h8 wA0[WI_P1 / 2], wA1[WI_P1 / 2], wB[WI_P2], wC[WI_P3], wD[WI_P4];       // the logits slice reuses wA0
-  kv_prefetch(0, 0);
+  int cgen = 0;                                       // compute_barrier generation
+  // Weight slices are requested right AFTER a hop has landed (B1), never right after a publish: a load issued behind a
+  // publish sits in the CU's in-order memory pipeline in front of the sweep waves' polls of the next hop.
   wload(wA0, p1_src(0));
   wload(wA1, p1_src(0) + (size_t)(WI_P1 / 2) * 64);
 
   for (int s = 0; s < a.nsteps; ++s) {
     const unsigned ep0 = (unsigned)s * (unsigned)EPS;
     for (int l = 0; l < a.L; ++l) {
-      const MegaLayerP lp = a.lp[l];
+      const float* lp = a.fpack + (size_t)l * FP_LAYER;
       relaunder(q);
-      wload(wB, pm_src(l, 0));
+      q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer;
+      MG_STAMP(q, 0);
       // ================= P1: q,k,v of head `head` for the own rows, K/V append, attention
       f4 p1_bias[2];
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int task = q.tid_c + 256 * it, tile = task >> 6, ln = task & 63;
-        p1_bias[it] = tile < 6 ? *(const f4*)(lp.qkv_b + (tile >> 1) * D + q.head * HD + 16 * (tile & 1) + 4 * (ln >> 4)) : (f4){0.f, 0.f, 0.f, 0.f};
+        p1_bias[it] = tile < 6 ? *(const f4*)(lp + FP_QKVB + (tile >> 1) * D + q.head * HD + 16 * (tile & 1) + 4 * (ln >> 4)) : (f4){0.f, 0.f, 0.f, 0.f};
       }
+      MG_STAMP(q, 1);
       MG_BAR();                                                          // B1: XS / XRES hold LN(y)
       if (*st_abort(q)) return;
       if (l == 0 && s > 0 && group_done(q)) return;
+      MG_STAMP(q, 2);
+      wload(wB, pm_src(l, 0));
       gemm_chunk<3>(q, wA0, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 6);
       gemm_chunk<3>(q, wA1, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 6 + 3);
-      MG_BAR();                                                          // B2
+      MG_STAMP(q, 3);
+      compute_barrier(q, cgen);                                          // B2 (compute waves only)
+      if (*st_abort(q)) return;
+      MG_STAMP(q, 4);
       {
         const f4* red = (const f4*)(smem + L_RED);
         _Float16* qkv_s = (_Float16*)(smem + L_QKV);
@@ -481,111 +699,53 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
             if (pos < a.smax) *(h4*)(const_cast<_Float16*>(kv_row_base(l, which - 1, r)) + (size_t)pos * HD + e) = ov;
           }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this layer's K/V image (LDS-DMA) has landed
+        MG_STAMP(q, 5);
       }
-      MG_BAR();                                                          // B3
-      {
-        // attention of own row ro = q.cw >> 1, keys dealt to the two waves of the row in 16-key groups
-        const int ro = q.cw >> 1, hw = q.cw & 1, r = 2 * ro + q.half;
-        const bool rv = r < R && st_active(q)[r];
-        const int n_old = rv ? st_kvlen(q)[r] : 0;
-        const int part = q.lane & 3, slot = q.lane >> 2;
-        const _Float16* qkv_s = (const _Float16*)(smem + L_QKV) + ro * 3 * HD;
-        float qf[8];
-        {
-          const h8 qv = *(const h8*)(qkv_s + part * 8);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) qf[i] = (float)qv[i] * scale;
-        }
-        float m = -INFINITY, lsum = 0.f, acc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-        auto consume = [&](const h8& kk, const h8& vv, bool ok) {
-          float sc = 0.f;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) sc += qf[i] * (float)kk[i];
-          sc += __shfl_xor(sc, 1, 64);
-          sc += __shfl_xor(sc, 2, 64);
-          if (ok) {
-            const float mn = fmaxf(m, sc);
-            const float corr = __expf(m - mn);
-            const float p = __expf(sc - mn);
-            lsum = lsum * corr + p;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = acc[i] * corr + p * (float)vv[i];
-            m = mn;
-          }
-        };
-        const unsigned char* kimg = smem + L_KV + (ro * 2 + 0) * KV_CAP * 64;
-        const unsigned char* vimg = smem + L_KV + (ro * 2 + 1) * KV_CAP * 64;
-        const int n_img = min(n_old, KV_CAP);
-        for (int j0 = hw * 16; j0 < n_img; j0 += 64) {
-          const int ja = j0 + slot, jb = j0 + 32 + slot;
-          const int jac = min(ja, KV_CAP - 1), jbc = min(jb, KV_CAP - 1);
-          const h8 ka = *(const h8*)(kimg + jac * 64 + part * 16), va = *(const h8*)(vimg + jac * 64 + part * 16);
-          const h8 kb = *(const h8*)(kimg + jbc * 64 + part * 16), vb = *(const h8*)(vimg + jbc * 64 + part * 16);
-          consume(ka, va, ja < n_img);
-          consume(kb, vb, jb < n_img);
-        }
-        if (n_old > KV_CAP) {                                            // long rows: the tail comes straight from HBM
-          const _Float16* kg_ = kv_row_base(l, 0, r) + part * 8;
-          const _Float16* vg_ = kv_row_base(l, 1, r) + part * 8;
-          for (int j0 = KV_CAP + hw * 16; j0 < n_old; j0 += 32) {
-            const int j = j0 + slot, jc = min(j, n_old - 1);
-            const h8 kk = __builtin_nontemporal_load((const h8*)(kg_ + (size_t)jc * HD));
-            const h8 vv = __builtin_nontemporal_load((const h8*)(vg_ + (size_t)jc * HD));
-            consume(kk, vv, j < n_old);
-          }
-        }
-        if (hw == 0) {                                                   // this step's own key / value
-          const h8 kk = *(const h8*)(qkv_s + HD + part * 8), vv = *(const h8*)(qkv_s + 2 * HD + part * 8);
-          consume(kk, vv, rv && slot == 0);
-        }
-        const float wm = wave_max(m);
-        const float f = (m == -INFINITY) ? 0.f : __expf(m - wm);
-        lsum *= f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] *= f;
-#pragma unroll
-        for (int o = 4; o < 64; o <<= 1) {
-          lsum += __shfl_xor(lsum, o, 64);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
-        }
-        float* s_m = (float*)(smem + L_ATT);
-        float* s_acc = s_m + 4;
-        if (q.lane < 4) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) s_acc[q.cw * 36 + q.lane * 8 + i] = acc[i];
-          if (q.lane == 0) { s_acc[q.cw * 36 + 32] = lsum; s_m[q.cw] = wm; }
-        }
-      }
+      MG_STAMP(q, 6);
+      compute_barrier(q, cgen);                                          // B3 (compute waves only)
+      if (*st_abort(q)) return;
+      MG_STAMP(q, 7);
+      attention_part<2>(a, q, l, q.cw);
+      MG_STAMP(q, 8);
       MG_BAR();                                                          // B4
+      MG_STAMP(q, 9);
       if (q.cw == 0) {
+        // combine the 2 waves of each own row; lane = ro * 32 + e
         const float* s_m = (const float*)(smem + L_ATT);
-        const float* s_acc = s_m + 4;
+        const float* s_acc = s_m + 8;
         const int ro = q.lane >> 5, e = q.lane & 31, r = 2 * ro + q.half;
-        const float m0 = s_m[2 * ro], m1 = s_m[2 * ro + 1], M = fmaxf(m0, m1);
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) M = fmaxf(M, s_m[2 * ro + w]);
         float o = 0.f;
         if (M != -INFINITY) {
-          const float e0 = m0 == -INFINITY ? 0.f : __expf(m0 - M), e1 = m1 == -INFINITY ? 0.f : __expf(m1 - M);
-          const float Lsum = s_acc[(2 * ro) * 36 + 32] * e0 + s_acc[(2 * ro + 1) * 36 + 32] * e1;
-          o = (s_acc[(2 * ro) * 36 + e] * e0 + s_acc[(2 * ro + 1) * 36 + e] * e1) / Lsum;
+          float Lsum = 0.f, num = 0.f;
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const float mw = s_m[2 * ro + w];
+            const float ew = mw == -INFINITY ? 0.f : __expf(mw - M);
+            Lsum += s_acc[(2 * ro + w) * 36 + 32] * ew;
+            num += s_acc[(2 * ro + w) * 36 + e] * ew;
+          }
+          o = num / Lsum;
         }
         const float o2 = __shfl_xor(o, 1, 64);
+        // 16 granules (one 128-B line) per own row, written by one wave instruction
         if (r < R && !(e & 1)) gstore(q.hop + HOP_B + r * 256 + (q.head * HD + e) / 2, ep0 + 4 * l + 2, pack_h2(o, o2));
       }
+      MG_STAMP(q, 10);
       relaunder(q);
-      // next layer's K/V image (the next step's layer 0 will hold one more position: appended above by this CU)
-      if (l + 1 < a.L) kv_prefetch(l + 1, 0);
-      else kv_prefetch(0, 1);
-      wload(wC, pm_src(l, WI_P2));
       // ================= P2: out-projection columns [16 member, +16) + bias + residual -> y1
-      f4 p_bias = *(const f4*)(lp.out_b + 16 * q.member + 4 * (q.lane >> 4));
+      f4 p_bias = *(const f4*)(lp + FP_OUTB + 16 * q.member + 4 * (q.lane >> 4));
+      MG_STAMP(q, 11);
       MG_BAR();                                                          // B1: AT holds the attention output
       if (*st_abort(q)) return;
+      MG_STAMP(q, 12);
+      wload(wC, pm_src(l, WI_P2));
       gemm_chunk<1>(q, wB, (const _Float16*)(smem + L_AT), XS_LD, q.cw, q.cw);
+      MG_STAMP(q, 13);
       MG_BAR();                                                          // B2
+      MG_STAMP(q, 14);
       if (q.cw == 0) {
         const f4* red = (const f4*)(smem + L_RED);
         const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
@@ -594,36 +754,56 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
           v += red[64 + q.lane]; v += red[128 + q.lane]; v += red[192 + q.lane];
           v += p_bias;
           v += *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) gstore(q.hop + HOP_C + r * 512 + n0 + i, ep0 + 4 * l + 3, __float_as_uint(v[i]));
+          *(f4*)((float*)(smem + L_STAGE) + r * 16 + 4 * (q.lane >> 4)) = v;
         }
+        // transposed through LDS (same wave): lane = row * 16 + column, so each row's 16 granules = one 128-B line
+        // written whole by ONE store instruction (scattered 8-B write-through stores made every hop 2-3x slower)
+        if (q.lane < R * 16)
+          gstore(q.hop + HOP_C + (q.lane >> 4) * 512 + 16 * q.member + (q.lane & 15), ep0 + 4 * l + 3,
+                 __float_as_uint(((const float*)(smem + L_STAGE))[q.lane]));
       }
       relaunder(q);
-      wload(wD, pm_src(l, WI_P2 + WI_P3));
       // ================= P3: FFN1 columns [64 member, +64), ReLU -> h
-      p_bias = *(const f4*)(lp.b1 + 64 * q.member + 16 * q.cw + 4 * (q.lane >> 4));
+      p_bias = *(const f4*)(lp + FP_B1 + 64 * q.member + 32 * (q.cw & 1) + 4 * (q.lane >> 4));       // tiles 2 (cw & 1), +1
+      const f4 p_bias2 = *(const f4*)(lp + FP_B1 + 64 * q.member + 32 * (q.cw & 1) + 16 + 4 * (q.lane >> 4));
+      MG_STAMP(q, 15);
       MG_BAR();                                                          // B1: XS / XRES hold LN1(y1)
       if (*st_abort(q)) return;
+      MG_STAMP(q, 16);
+      wload(wD, pm_src(l, WI_P2 + WI_P3));
       gemm_chunk<4>(q, wC, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 4);
+      MG_STAMP(q, 17);
       MG_BAR();                                                          // B2
-      {
+      MG_STAMP(q, 18);
+      if (q.cw < 2) {
+        // waves 0 and 1 reduce tiles {0, 1} and {2, 3}: 32 columns = 16 half-pair granules = one 128-B line per row
         const f4* red = (const f4*)(smem + L_RED);
-        const int tile = q.cw, r = q.lane & 15, n0 = 64 * q.member + 16 * tile + 4 * (q.lane >> 4);
+        const int r = q.lane & 15;
+        unsigned* stage = (unsigned*)(smem + L_STAGE) + q.cw * 256;
         if (r < R) {
-          f4 v = red[(0 * 4 + tile) * 64 + q.lane];
-          v += red[(1 * 4 + tile) * 64 + q.lane]; v += red[(2 * 4 + tile) * 64 + q.lane]; v += red[(3 * 4 + tile) * 64 + q.lane];
-          v += p_bias;
-          gstore(q.hop + HOP_D + r * 1024 + n0 / 2, ep0 + 4 * l + 4, pack_h2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)));
-          gstore(q.hop + HOP_D + r * 1024 + n0 / 2 + 1, ep0 + 4 * l + 4, pack_h2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)));
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const int tile = 2 * q.cw + tt;
+            f4 v = red[(0 * 4 + tile) * 64 + q.lane];
+            v += red[(1 * 4 + tile) * 64 + q.lane]; v += red[(2 * 4 + tile) * 64 + q.lane]; v += red[(3 * 4 + tile) * 64 + q.lane];
+            v += tt == 0 ? p_bias : p_bias2;
+            const int w0 = r * 16 + tt * 8 + 2 * (q.lane >> 4);
+            stage[w0] = pack_h2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+            stage[w0 + 1] = pack_h2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+          }
         }
+        if (q.lane < R * 16)
+          gstore(q.hop + HOP_D + (q.lane >> 4) * 1024 + 32 * q.member + 16 * q.cw + (q.lane & 15), ep0 + 4 * l + 4, stage[q.lane]);
       }
       relaunder(q);
-      if (l + 1 < a.L) wload(wA0, p1_src(l + 1));
-      else wload(wA0, a.lpack + (((size_t)q.member * 4 + q.cw) * WI_LG * 512) / 8 + q.lane);
       // ================= P4: FFN2 columns [16 member, +16) over K = 2048 (16 chunks, summed in chunk order) -> y2
-      p_bias = *(const f4*)(lp.b2 + 16 * q.member + 4 * (q.lane >> 4));
+      p_bias = *(const f4*)(lp + FP_B2 + 16 * q.member + 4 * (q.lane >> 4));
+      MG_STAMP(q, 19);
       MG_BAR();                                                          // B1: HS holds the FFN hidden
       if (*st_abort(q)) return;
+      MG_STAMP(q, 20);
+      if (l + 1 < a.L) wload(wA0, p1_src(l + 1));
+      else wload(wA0, a.lpack + (((size_t)q.member * 4 + q.cw) * WI_LG * 512) / 8 + q.lane);
       {
         const int rowl = q.lane & 15, kg = q.lane >> 4;
         f4* red = (f4*)(smem + L_RED);
@@ -638,7 +818,11 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
           __builtin_amdgcn_sched_barrier(0);       // keep the 16 operand reads from being hoisted in front of the first MFMA
         }
       }
+      // second half of the next P1 slice: FFN2's slice is dead now, and the request is still in front of the publish
+      wload(wA1, p1_src(l + 1 < a.L ? l + 1 : 0) + (size_t)(WI_P1 / 2) * 64);
+      MG_STAMP(q, 21);
       MG_BAR();                                                          // B2
+      MG_STAMP(q, 22);
       if (q.cw == 0) {
         const f4* red = (const f4*)(smem + L_RED);
         const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
@@ -649,12 +833,14 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
           v += p_bias;
           v += *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
           // y2 feeds hop A of the next layer, or hop A' (the logits' LayerNorm) after the last layer
-          const unsigned ep = l + 1 < a.L ? ep0 + 4 * (l + 1) + 1 : ep0 + 4 * a.L + 1;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) gstore(q.hop + HOP_A + r * 512 + n0 + i, ep, __float_as_uint(v[i]));
+          *(f4*)((float*)(smem + L_STAGE) + r * 16 + 4 * (q.lane >> 4)) = v;
         }
+        const unsigned ep = l + 1 < a.L ? ep0 + 4 * (l + 1) + 1 : ep0 + 4 * a.L + 1;
+        if (q.lane < R * 16)
+          gstore(q.hop + HOP_A + (q.lane >> 4) * 512 + 16 * q.member + (q.lane & 15), ep,
+                 __float_as_uint(((const float*)(smem + L_STAGE))[q.lane]));
       }
-      wload(wA1, p1_src(l + 1 < a.L ? l + 1 : 0) + (size_t)(WI_P1 / 2) * 64);   // second half of the next P1 slice
+      MG_STAMP(q, 23);
     }
     // ================= tail: logits split over the members (tiles member, member + 32, and tile 64 on member 0)
     const unsigned epE = ep0 + 4 * a.L + 2;
@@ -662,20 +848,20 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
     MG_BAR();                                                            // B1: XS holds LN2(y) of the last layer
     if (*st_abort(q)) return;
     gemm_chunk<3>(q, wA0, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 3);
-    wload(wA0, p1_src(0));                                               // next step's layer 0 (two hops away; wA1 is already there)
+    wload(wA0, p1_src(0));                                               // next step's layer 0 (two hops away; wA1 is there already)
     MG_BAR();                                                            // B2
     if (q.cw < 3) {
       const f4* red = (const f4*)(smem + L_RED);
       const int t = q.cw, r = q.lane & 15;
       const int tile = t == 0 ? q.member : (t == 1 ? q.member + 32 : 64);
-      if (r < R && (t < 2 || q.member == 0)) {
+      float* stage = (float*)(smem + L_STAGE) + q.cw * 256;
+      if (r < R) {
         f4 v = red[(0 * 3 + t) * 64 + q.lane];
         v += red[(1 * 3 + t) * 64 + q.lane]; v += red[(2 * 3 + t) * 64 + q.lane]; v += red[(3 * 3 + t) * 64 + q.lane];
-        const int n0 = 16 * tile + 4 * (q.lane >> 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (n0 + i < V) gstore(q.hop + HOP_E + r * VPAD + n0 + i, epE, __float_as_uint(v[i]));
+        *(f4*)(stage + r * 16 + 4 * (q.lane >> 4)) = v;
       }
+      if (q.lane < R * 16 && (t < 2 || q.member == 0) && 16 * tile + (q.lane & 15) < V)
+        gstore(q.hop + HOP_E + (q.lane >> 4) * VPAD + 16 * tile + (q.lane & 15), epE, __float_as_uint(stage[q.lane]));
     }
   }
 }
@@ -693,6 +879,8 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   if (c.R == 0) return;
   c.hop = (gu64*)a.hop + (size_t)c.group * HOP_GROUP;
   c.err = (gu32*)a.err;
+  c.prof = a.prof ? a.prof + ((size_t)blockIdx.x * 8 + c.wave) * 32 : nullptr;
+  c.prof_on = false;
   const int lane = c.lane, R = c.R;
   const StepParams sp = *a.sp;
 

@@ -48,7 +48,7 @@ class ConvDesc(C.Structure):
                 ("pre_slope", C.c_float), ("post_act", C.c_int), ("scale", C.c_float), ("accumulate", C.c_int),
                 ("out_f32", C.c_int), ("ups_u", C.c_int), ("ups_pad", C.c_int),
                 ("Z", C.c_int), ("xz", C.c_longlong), ("wz", C.c_longlong), ("yz", C.c_longlong),
-                ("ldx", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int), ("gate", C.c_void_p)]
+                ("ldx", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int), ("gate", C.c_void_p), ("bz", C.c_int)]
 
 
 _SIGS = {
@@ -103,6 +103,10 @@ _SIGS = {
     "gsv_op_flash_rel96": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "gsv_op_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
+    "gsv_op_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "gsv_op_magnitude": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "gsv_op_channel_norm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_void_p]),
     "gsv_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_float, C.c_int, C.c_void_p]),
     "gsv_op_decode_attn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -246,6 +246,7 @@ typedef struct {
   /* optional (0 = defaults): batched GEMM over Z slices with element strides, explicit leading dims */
   int Z; long long xz, wz, yz; int ldx, ldw, ldy;
   const float* gate;   /* optional per-output-channel gate: y = ((W x + b) * gate + res) * scale */
+  int bz;              /* grouped convs (Z > 1): element stride of bias between slices (0 = one bias shared by all) */
 } gsv_conv_desc;
 /* fused softmax attention of the DiT blocks alone (fp16, head dim 64): qkv [dev] f16 [T][3*heads*64] (q | k | v column
  * blocks), vt_scratch [dev] heads*64*ceil32(T) halfs, out [dev] f16 [T][heads*64] */
@@ -265,6 +266,17 @@ int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream);
 /* y = LN(x (+res)) over the last dim C; all buffers of `dtype`, gamma/beta fp32 */
 int gsv_op_layernorm(const void* x, const void* res, const float* gamma, const float* beta, void* y, int rows,
                      int C, float eps, int dtype, gsv_stream_t stream);
+/* reference-audio front-end helpers (host orchestration in gsv/module/mel_processing.py and
+ * gsv/feature_extractor/cnhubert.py, the GEMMs are gsv_op_conv1d):
+ *  gsv_op_frame: out[t][k] = x[reflect(t*hop + k - pad)], k < frame_len, zero up to ld; x [dev] fp32 [n]; out [T_out][ld] of dtype
+ *    (torch.stft's reflect framing, reference module/mel_processing.py:55-71; pad = 0: the operand of a strided Conv1d(1, C, k))
+ *  gsv_op_magnitude: re_im [dev] fp32 [T][2*bins] (re | im) -> spec [dev] fp32 [bins][T] = sqrt(re^2 + im^2 + eps)  (:73)
+ *  gsv_op_channel_norm: channels-last [T][C]: per-channel mean / biased variance over T, affine, activation (ACT codes of
+ *    gsv_conv_desc.post_act) -- torch.nn.GroupNorm(C, C) of the HuBERT feature extractor; scratch [dev] 128*C floats */
+int gsv_op_frame(const float* x, int n, int frame_len, int hop, int pad, int ld, int T_out, void* out, int dtype, gsv_stream_t stream);
+int gsv_op_magnitude(const float* re_im, int T, int bins, float eps, float* spec, gsv_stream_t stream);
+int gsv_op_channel_norm(const void* x, int T, int C, const float* gamma, const float* beta, float eps, int act, float* scratch,
+                        void* y, int dtype, gsv_stream_t stream);
 /* sampling kernel alone: logits [dev] fp32 [B][vocab], prev [dev] int32 [B][prev_len], noise [dev]
  * fp32 [B][vocab] or NULL; outputs [dev] int32 [B]: sampled token, argmax of penalised logits */
 int gsv_op_sample(const float* logits, int B, int vocab, int vocab_eff, const int32_t* prev, int prev_len,

@@ -130,3 +130,24 @@ def test_decode_encp_single_token():
     ref, _ = VitsOracle(sd, cfg).decode_encp(codes, text, refer, speed=1, version="v3")
     assert tuple(fea.shape) == tuple(ref.shape) == (1, 512, 3)
     assert (fea.cpu() - ref).abs().max() <= 5e-4
+
+
+def test_cfm_full_depth_at_chunk_length_vs_oracle():
+    """BASELINE configs[3] shape: the full DiT (1024 x 22 blocks, 16 heads x 64) over one 934-frame chunk with a 468-frame
+    prompt, 2 Euler steps, fp32 engine vs the CPU oracle (0.9 TFLOP on the host).  Depth and length are where a fused
+    attention / split-K GEMM indexing error would show; max-abs <= 5e-3 on mels of rms ~1 (22 blocks deep)."""
+    from gsv import synthetic as S
+    from oracle import cfm_oracle
+    cfg = dict(S.DIT_V3_CONFIG)
+    sd = S.make_dit_state_dict(cfg, seed=9)
+    B, T, Tp = 1, 934, 468
+    mu = S.hash_symmetric("full_mu", (B, T, cfg["text_dim"]), 1.0, 1)
+    prompt = S.hash_symmetric("full_prompt", (1, cfg["mel_dim"], Tp), 1.0, 2)
+    noise = S.hash_normal("full_noise", (B, cfg["mel_dim"], T), 3)
+    torch.set_num_threads(8)
+    ref = cfm_oracle.cfm_inference(sd, cfg, mu, prompt, 2, noise.clone())
+    out = _cfm(cfg, sd, torch.float32).inference(mu.to(DEV), None, prompt.to(DEV), 2, noise=noise).cpu()
+    err = (out - ref).abs().max().item()
+    print(f"[parity] depth-22 DiT, T=934, 2 steps: max-abs error {err:.2e} (mel rms {ref.pow(2).mean().sqrt():.3f})")
+    assert out.shape == ref.shape == (1, 100, 934)
+    assert err <= 5e-3

@@ -215,3 +215,30 @@ def test_capacity_limits_chunking_arena_bound_and_loud_errors():
     rc = _lib.lib().gsv_t2s_prefill(eng._h, phones.data_ptr(), C.cast(lens, C.c_void_p), len(xs), None, pr.data_ptr(), P,
                                     C.c_void_p(eng.stream.cuda_stream))
     assert rc != 0 and b"batch" in _lib.lib().gsv_last_error().lower()
+
+
+def test_fp32_engine_equals_oracle_at_benchmark_shape():
+    """BASELINE configs[1] shape, engine-level: 3 rows of the benchmark's own workload (80 phonemes, 100 prompt tokens),
+    ALL 100 generated tokens (K/V cache 180 -> 280, i.e. through the second batch of the decode-attention kernel's key
+    groups): the fp32 engine's ids equal the CPU oracle's, which is pinned against the reference class on the same
+    architecture (t2s_v2_greedy golden).  Rows whose oracle top-2 margin stays clear must be identical to the last token;
+    a row may only diverge at a step where the oracle's own margin is below 1e-3 (fp32 summation order)."""
+    from gsv import synthetic as S
+    from oracle.t2s_oracle import T2SOracle
+    cfg = S.T2S_V2_CONFIG
+    sd = S.make_t2s_state_dict(cfg, seed=0, suppress_eos=True)
+    n = 3
+    utt = S.make_utterances(32)
+    items = utt["items"][:n]
+    xs = [torch.tensor(it["all_phones"]) for it in items]
+    berts = [it["bert"] for it in items]
+    prompts = utt["prompt_semantic"].unsqueeze(0).expand(n, -1).contiguous()
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, early_stop_num=100, repetition_penalty=1.35)
+    torch.set_num_threads(8)
+    oys, oidx = T2SOracle(sd, cfg).infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    eng = _engine(cfg, sd, torch.float32, max_batch=4, max_seq=320)
+    ys, idxs = eng.infer_panel_batch_infer([x.to(DEV) for x in xs], None, prompts.to(DEV), [b.to(DEV) for b in berts], **kw)
+    assert idxs == oidx == [100] * n
+    same = [a.cpu().tolist() == b.tolist() for a, b in zip(ys, oys)]
+    print(f"[parity] fp32 engine vs oracle at the benchmark shape: {sum(same)}/{n} rows identical over 100 tokens")
+    assert all(same)

@@ -173,3 +173,29 @@ def test_v2pro_conditioning_matches_reference():
     with pytest.raises(ValueError):
         c2 = cases.vits_case_inputs(cases.VITS_CASES["vits_small"])
         v2.decode(c2[2].to(DEV), c2[3].to(DEV), [r.to(DEV) for r in c2[4]], sv_emb=sv[0])                  # not a v2Pro model
+
+
+def test_fp32_folded_decode_at_benchmark_length_vs_oracle():
+    """BASELINE configs[1] SoVITS shape at engine level: two utterances of 100 tokens folded into the time axis (400 frames,
+    256 000 samples, enc_p attention across both sentences) through the full v2 architecture, fp32 engine vs the CPU oracle
+    (pinned against the reference class on vits_v2): waveform max-abs error <= 1e-4."""
+    from gsv import synthetic as S
+    from gsv.module.models import SynthesizerTrn
+    from oracle.vits_oracle import VitsOracle
+    cfg = S.VITS_V2_CONFIG
+    sd = S.make_vits_state_dict(cfg, seed=0)
+    d = cfg["data"]
+    v = SynthesizerTrn(d["filter_length"] // 2 + 1, cfg["train"]["segment_size"] // d["hop_length"], n_speakers=d["n_speakers"],
+                       version="v2", device="cuda:0", dtype=torch.float32, n_symbols=cfg.get("n_symbols"), **cfg["model"])
+    v.load_state_dict(sd)
+    codes = torch.from_numpy(S.hash_ints("bench_codes", 200, 1024, 0)).view(1, 1, -1)
+    text = torch.from_numpy(S.hash_ints("bench_text", 80, 732, 0)).view(1, -1)
+    refer = S.make_refer_spec()
+    noise = S.hash_normal("bench_vits_noise", (cfg["model"]["inter_channels"], 400), 0)
+    torch.set_num_threads(8)
+    ref = VitsOracle(sd, cfg).decode(codes, text, [refer], noise=noise)
+    wav = v.decode(codes.to("cuda:0"), text.to("cuda:0"), [refer.to("cuda:0")], noise=noise).float().cpu()
+    assert wav.shape == ref.shape == (1, 1, 400 * 640)
+    err = (wav - ref).abs().max().item()
+    print(f"[parity] fp32 SoVITS folded decode, 400 frames: max-abs error {err:.2e} (waveform rms {ref.pow(2).mean().sqrt():.3f})")
+    assert err <= 1e-4
