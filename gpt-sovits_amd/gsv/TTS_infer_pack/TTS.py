@@ -111,6 +111,10 @@ class TTS:
         self._t2s_state = None
         self._vits_state = None
         self.vocoder = None
+        self.cnhuhbert_model = None
+        self.bert_model = None
+        from .TextPreprocessor import TextPreprocessor
+        self.text_preprocessor = TextPreprocessor(bert_fn=None, device="cpu")      # reference TTS.py:431-433
         self.vocoder_configs: dict = {"sr": None, "T_ref": None, "T_chunk": None, "upsample_rate": None, "overlapped_len": None}
 
     # ---- weights (reference TTS.py:484-603) ------------------------------------------------
@@ -208,6 +212,70 @@ class TTS:
         self.prompt_cache["phones"] = phones
         self.prompt_cache["bert_features"] = bert_features
         self.prompt_cache["norm_text"] = norm_text
+
+    # ---- reference-audio front-end (reference TTS.py:462-482, 737-819) -------------------------------------------
+    def init_cnhuhbert_weights(self, base_path: Optional[str] = None, state_dict: Optional[dict] = None):
+        """HuBERT-base content encoder (reference TTS.py:462-470; feature_extractor/cnhubert.py).  `state_dict` = a
+        transformers.HubertModel state dict (tests, synthetic weights); `base_path` = directory with pytorch_model.bin /
+        model.safetensors."""
+        from ..feature_extractor.cnhubert import CNHubert
+        self.cnhuhbert_model = CNHubert(base_path, device=self.configs.device, dtype=torch.float16, state_dict=state_dict)
+
+    def set_ref_audio(self, ref_audio_path: str):
+        """reference TTS.py:737-747: prompt semantic tokens (HuBERT -> ssl_proj -> VQ) and the reference spectrogram."""
+        self._set_prompt_semantic(ref_audio_path)
+        self._set_ref_spec(ref_audio_path)
+        self.prompt_cache["ref_audio_path"] = ref_audio_path
+
+    def _set_ref_spec(self, ref_audio_path: str):
+        spec_audio = self._get_ref_spec(ref_audio_path)
+        if self.prompt_cache["refer_spec"] in [[], None]:
+            self.prompt_cache["refer_spec"] = [spec_audio]
+        else:
+            self.prompt_cache["refer_spec"][0] = spec_audio
+        if self.vits_model is not None:
+            self.vits_model.invalidate_refer()
+
+    def _get_ref_spec(self, ref_audio_path: str):
+        """reference TTS.py:761-800: mono, resampled to the model rate, divided by min(2, peak) when the peak exceeds 1,
+        spectrogram_torch(filter_length, hop_length, win_length, center=False)."""
+        from ..audio_io import load_wav, resample
+        from ..module.mel_processing import spectrogram_torch
+        if getattr(self.vits_model, "is_v2pro", False):
+            raise NotImplementedError("v2Pro / v2ProPlus need the ERes2NetV2 speaker embedding (sv.py:11-32), which is not built: "
+                                      "use set_prompt_cache(..., sv_emb=...)")
+        raw, raw_sr = load_wav(ref_audio_path)
+        self.prompt_cache["raw_sr"] = raw_sr
+        if raw.shape[0] == 2:
+            raw = raw.mean(0, keepdims=True)
+        audio = torch.from_numpy(resample(raw[:1], raw_sr, self.configs.sampling_rate)).to(self.configs.device)
+        self.prompt_cache["raw_audio"] = audio
+        maxx = float(audio.abs().max())
+        if maxx > 1:
+            audio = audio / min(2.0, maxx)
+        spec = spectrogram_torch(audio, self.configs.filter_length, self.configs.sampling_rate, self.configs.hop_length,
+                                 self.configs.win_length, center=False)
+        if self.configs.is_half:
+            spec = spec.half()
+        return spec, None
+
+    def _set_prompt_semantic(self, ref_wav_path: str):
+        """reference TTS.py:802-819: 16 kHz audio (3..10 s or OSError) + 0.3 s of silence -> HuBERT last_hidden_state ->
+        SynthesizerTrn.extract_latent codes."""
+        from ..audio_io import load_wav, resample
+        if getattr(self, "cnhuhbert_model", None) is None:
+            raise RuntimeError("init_cnhuhbert_weights() first")
+        if self.vits_model is None:
+            raise RuntimeError("init_vits_weights() first")
+        raw, raw_sr = load_wav(ref_wav_path)
+        wav16k = resample(raw.mean(0), raw_sr, 16000)
+        if wav16k.shape[0] > 160000 or wav16k.shape[0] < 48000:
+            raise OSError("参考音频在3~10秒范围外，请更换！")
+        zero_wav = np.zeros(int(self.configs.sampling_rate * 0.3), dtype=np.float32)
+        wav = torch.from_numpy(np.concatenate([wav16k, zero_wav])).to(self.configs.device)
+        hubert_feature = self.cnhuhbert_model.model(wav.unsqueeze(0))["last_hidden_state"].transpose(1, 2)
+        codes = self.vits_model.extract_latent(hubert_feature)
+        self.prompt_cache["prompt_semantic"] = codes[0, 0].to(self.configs.device)
 
     def stop(self):
         self.stop_flag = True
@@ -478,17 +546,46 @@ class TTS:
         try:
             if self.t2s_model is None or self.vits_model is None:
                 raise RuntimeError("init_t2s_weights / init_vits_weights first")
+            # ---- reference audio and prompt text (reference TTS.py:1078-1120)
+            ref_audio_path = inputs.get("ref_audio_path")
+            prompt_text, prompt_lang = inputs.get("prompt_text"), inputs.get("prompt_lang", "")
+            if ref_audio_path in [None, ""] and inputs.get("segments") is None and "text" in inputs and (
+                    self.prompt_cache["prompt_semantic"] is None or self.prompt_cache["refer_spec"] in [None, []]):
+                raise ValueError("ref_audio_path cannot be empty, when the reference audio is not set using set_ref_audio()")
+            if ref_audio_path not in [None, ""] and ref_audio_path != self.prompt_cache["ref_audio_path"]:
+                if not os.path.exists(ref_audio_path):
+                    raise ValueError(f"{ref_audio_path} not exists")
+                self.set_ref_audio(ref_audio_path)
+            if prompt_text not in [None, ""]:
+                from .text_segmentation_method import splits
+                if prompt_lang not in self.configs.languages:
+                    raise ValueError(f"prompt_lang {prompt_lang!r} is not one of {self.configs.languages}")
+                prompt_text = prompt_text.strip("\n")
+                if prompt_text[-1] not in splits:
+                    prompt_text += "。" if prompt_lang != "en" else "."
+                if self.prompt_cache["prompt_text"] != prompt_text:
+                    phones, bert_features, norm_text = self.text_preprocessor.segment_and_extract_feature_for_text(
+                        prompt_text, prompt_lang, self.configs.version)
+                    self.prompt_cache.update(prompt_text=prompt_text, prompt_lang=prompt_lang, phones=phones,
+                                             bert_features=bert_features, norm_text=norm_text)
+            elif "prompt_text" in inputs and self.configs.use_vocoder:
+                raise NO_PROMPT_ERROR("prompt_text cannot be empty when using SoVITS_V3")
             if not self.prompt_cache["refer_spec"] or (self.prompt_cache["prompt_semantic"] is None
                                                        and self.prompt_cache["phones"] is not None):
                 raise NO_PROMPT_ERROR("set_prompt_cache() first (reference: ref_audio_path is required)")
             t0 = time.perf_counter()
             segments = inputs.get("segments")
             if segments is None:
-                if self.text_frontend is None:
-                    raise NotImplementedError("raw text needs a text_frontend callable (G2P/BERT are outside the "
-                                              "hot-path scope); pass inputs['segments'] with phones/bert instead")
-                segments = self.text_frontend(inputs.get("text", ""), inputs.get("text_lang", ""),
-                                              inputs.get("text_split_method", "cut0"))
+                # reference TTS.py:1018-1024, 1100-1135: raw text through the TextPreprocessor (G2P back-ends are plug-ins,
+                # gsv.text.cleaner.register_g2p); a `text_frontend` callable replaces it wholesale
+                text, text_lang = inputs.get("text", ""), inputs.get("text_lang", "")
+                method = inputs.get("text_split_method", "cut0")
+                if self.text_frontend is not None:
+                    segments = self.text_frontend(text, text_lang, method)
+                else:
+                    if text_lang not in self.configs.languages:
+                        raise ValueError(f"text_lang {text_lang!r} is not one of {self.configs.languages}")
+                    segments = self.text_preprocessor.preprocess(text, text_lang, method, self.configs.version)
             if len(segments) == 0:
                 yield 16000, np.zeros(16000, dtype=np.int16)
                 return

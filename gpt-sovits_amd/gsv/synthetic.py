@@ -521,3 +521,54 @@ def make_vits_v3_state_dict(config=None, seed: int = 0, dit_cfg=None) -> "Ordere
         for k, v in make_dit_state_dict(dit_cfg, seed).items():
             sd["cfm.estimator." + k] = v
     return sd
+
+
+# --------------------------------------------------------------------------
+# HuBERT-base (reference feature_extractor/cnhubert.py: transformers.HubertModel, HubertConfig defaults)
+# --------------------------------------------------------------------------
+def make_hubert_state_dict(seed: int = 0, layers: int = 12, hidden: int = 768, ffn: int = 3072, conv_dim: int = 512,
+                           pos_kernel: int = 128, pos_groups: int = 16) -> "OrderedDict[str, torch.Tensor]":
+    """fp32 state dict with transformers.HubertModel's key names (weight-normed positional conv as
+    parametrizations.weight.original0 / original1)."""
+    sd = OrderedDict()
+    kernels = (10, 3, 3, 3, 3, 2, 2)
+    for i, k in enumerate(kernels):
+        cin = 1 if i == 0 else conv_dim
+        # gain > 1 keeps the activations from shrinking through seven GELU layers
+        sd[f"feature_extractor.conv_layers.{i}.conv.weight"] = _w(f"hubert.conv{i}", (conv_dim, cin, k), cin * k, 2.0, seed)
+    sd["feature_extractor.conv_layers.0.layer_norm.weight"] = 1.0 + hash_symmetric("hubert.gn.w", (conv_dim,), 0.1, seed)
+    sd["feature_extractor.conv_layers.0.layer_norm.bias"] = _b("hubert.gn.b", conv_dim, 0.1, seed)
+    sd["feature_projection.layer_norm.weight"] = 1.0 + hash_symmetric("hubert.fpln.w", (conv_dim,), 0.1, seed)
+    sd["feature_projection.layer_norm.bias"] = _b("hubert.fpln.b", conv_dim, 0.1, seed)
+    sd["feature_projection.projection.weight"] = _w("hubert.fp.w", (hidden, conv_dim), conv_dim, 1.0, seed)
+    sd["feature_projection.projection.bias"] = _b("hubert.fp.b", hidden, 0.05, seed)
+    cg = hidden // pos_groups
+    sd["encoder.pos_conv_embed.conv.bias"] = _b("hubert.pos.b", hidden, 0.05, seed)
+    sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = 0.5 + hash_symmetric("hubert.pos.g", (1, 1, pos_kernel), 0.2, seed)
+    sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = _w("hubert.pos.v", (hidden, cg, pos_kernel), cg * pos_kernel, 1.0, seed)
+    sd["encoder.layer_norm.weight"] = 1.0 + hash_symmetric("hubert.encln.w", (hidden,), 0.1, seed)
+    sd["encoder.layer_norm.bias"] = _b("hubert.encln.b", hidden, 0.1, seed)
+    for i in range(layers):
+        p = f"encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[p + f"attention.{nm}.weight"] = _w(p + nm + ".w", (hidden, hidden), hidden, 1.0, seed)
+            sd[p + f"attention.{nm}.bias"] = _b(p + nm + ".b", hidden, 0.05, seed)
+        sd[p + "layer_norm.weight"] = 1.0 + hash_symmetric(p + "ln1.w", (hidden,), 0.1, seed)
+        sd[p + "layer_norm.bias"] = _b(p + "ln1.b", hidden, 0.1, seed)
+        sd[p + "feed_forward.intermediate_dense.weight"] = _w(p + "f1.w", (ffn, hidden), hidden, 1.0, seed)
+        sd[p + "feed_forward.intermediate_dense.bias"] = _b(p + "f1.b", ffn, 0.05, seed)
+        sd[p + "feed_forward.output_dense.weight"] = _w(p + "f2.w", (hidden, ffn), ffn, 1.0, seed)
+        sd[p + "feed_forward.output_dense.bias"] = _b(p + "f2.b", hidden, 0.05, seed)
+        sd[p + "final_layer_norm.weight"] = 1.0 + hash_symmetric(p + "ln2.w", (hidden,), 0.1, seed)
+        sd[p + "final_layer_norm.bias"] = _b(p + "ln2.b", hidden, 0.1, seed)
+    return sd
+
+
+def make_waveform(n: int, seed: int = 0, sr: int = 16000) -> torch.Tensor:
+    """a speech-like test signal in [-0.5, 0.5]: a few amplitude-modulated partials + hash noise, [n] fp32"""
+    t = np.arange(n, dtype=np.float64) / sr
+    f0 = 110.0 + 40.0 * np.sin(2 * np.pi * 0.7 * t)
+    ph = 2 * np.pi * np.cumsum(f0) / sr
+    y = sum(np.sin(k * ph + 0.3 * k) / k for k in range(1, 9)) * (0.6 + 0.4 * np.sin(2 * np.pi * 3.1 * t))
+    y = 0.25 * y / np.abs(y).max() + 0.05 * (hash_uniform("wave_noise", n, seed).astype(np.float64) - 0.5)
+    return torch.from_numpy(y.astype(np.float32))

@@ -135,7 +135,7 @@ def test_decode_encp_single_token():
 def test_cfm_full_depth_at_chunk_length_vs_oracle():
     """BASELINE configs[3] shape: the full DiT (1024 x 22 blocks, 16 heads x 64) over one 934-frame chunk with a 468-frame
     prompt, 2 Euler steps, fp32 engine vs the CPU oracle (0.9 TFLOP on the host).  Depth and length are where a fused
-    attention / split-K GEMM indexing error would show; max-abs <= 5e-3 on mels of rms ~1 (22 blocks deep)."""
+    attention / split-K GEMM indexing error would show; max-abs <= 5e-4 on mels of rms ~1 (measured 7.6e-6)."""
     from gsv import synthetic as S
     from oracle import cfm_oracle
     cfg = dict(S.DIT_V3_CONFIG)
@@ -150,4 +150,4 @@ def test_cfm_full_depth_at_chunk_length_vs_oracle():
     err = (out - ref).abs().max().item()
     print(f"[parity] depth-22 DiT, T=934, 2 steps: max-abs error {err:.2e} (mel rms {ref.pow(2).mean().sqrt():.3f})")
     assert out.shape == ref.shape == (1, 100, 934)
-    assert err <= 5e-3
+    assert err <= 5e-4

@@ -1,0 +1,95 @@
+"""GPU: the reference-audio front-end through the C ABI's op entry points:
+`spectrogram_torch` against the reference function's outputs (tests/golden/spec_*.npz), the HuBERT-base engine against
+`transformers.HubertModel` (the class the reference's CNHubert wraps) on synthetic weights (tests/golden/hubert_base.npz),
+and `TTS.set_ref_audio` end to end from a WAV file."""
+import os
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("name,n,seed", [("spec_32k_half_s", 16000, 0), ("spec_32k_ragged", 22001, 1), ("spec_short", 1500, 2)])
+def test_spectrogram_matches_reference(name, n, seed):
+    """fp32 DFT-as-GEMM vs torch.stft in the reference function: values up to ~75; max-abs <= 5e-4, relative rms <= 5e-6."""
+    from gsv import synthetic as S
+    from gsv.module.mel_processing import spectrogram_torch
+    y = S.make_waveform(n, seed, sr=32000).unsqueeze(0).to(DEV)
+    spec = spectrogram_torch(y, 2048, 32000, 640, 2048, center=False).cpu().numpy()
+    g = load_golden(name)["spec"]
+    assert spec.shape == g.shape
+    err = np.abs(spec - g).max()
+    rel = np.sqrt(((spec - g) ** 2).mean() / (g ** 2).mean())
+    print(f"[frontend] {name}: max-abs {err:.2e}, relative rms {rel:.2e}")
+    assert err <= 5e-4 and rel <= 5e-6
+    with pytest.raises(ValueError):
+        spectrogram_torch(y[:, :500], 2048, 32000, 640, 2048)          # shorter than the reflect padding
+    with pytest.raises(NotImplementedError):
+        spectrogram_torch(y, 2048, 32000, 640, 2048, center=True)
+
+
+def test_hubert_matches_transformers_model():
+    """fp16 engine vs transformers.HubertModel fp32 on the same synthetic weights and waveform: last_hidden_state of rms 1.0,
+    64 frames x 768; bar: relative rms <= 0.5 %, max-abs <= 3e-2 (measured 0.14 %, 6.8e-3) (fp16 activations through 7 convs + 12 post-LN layers)."""
+    from gsv import synthetic as S
+    from gsv.feature_extractor.cnhubert import CNHubert
+    g = load_golden("hubert_base")
+    ref = g["last_hidden_state"].astype(np.float32)
+    m = CNHubert(device=DEV, state_dict=S.make_hubert_state_dict(seed=0))
+    wav = S.make_waveform(20800, 7).unsqueeze(0).to(DEV)
+    out = m.model(wav)["last_hidden_state"]
+    assert tuple(out.shape) == (1, 64, 768)
+    o = out[0].float().cpu().numpy()
+    rel = np.sqrt(((o - ref) ** 2).mean() / (ref ** 2).mean())
+    err = np.abs(o - ref).max()
+    print(f"[frontend] HuBERT last_hidden_state: relative rms {rel:.3e}, max-abs {err:.3e}")
+    assert rel <= 5e-3 and err <= 3e-2
+    out2 = m.model(wav)["last_hidden_state"]
+    assert torch.equal(out, out2)
+    with pytest.raises(ValueError):
+        m.model(wav[:, :300])
+
+
+def _write_wav(path, x, sr):
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr)
+        f.writeframes((np.clip(x, -1, 1) * 32767).astype("<i2").tobytes())
+
+
+def test_set_ref_audio_end_to_end(tmp_path):
+    """WAV file -> resample -> HuBERT -> ssl_proj + VQ codes (prompt_semantic) and spectrogram (refer_spec), then a whole
+    TTS.run on that prompt; the 3-10 s guard raises OSError like the reference (TTS.py:802-803)."""
+    from gsv import synthetic as S
+    from gsv.TTS_infer_pack.TTS import TTS
+    tts = TTS({"device": DEV, "is_half": True, "version": "v2", "max_batch": 4, "max_seq": 600})
+    tts.init_t2s_weights(state={"weight": S.make_t2s_state_dict(S.T2S_V2_CONFIG, seed=0, suppress_eos=True), "config": S.T2S_V2_CONFIG})
+    tts.init_vits_weights(state={"weight": S.make_vits_state_dict(S.VITS_V2_CONFIG, seed=0), "config": dict(S.VITS_V2_CONFIG)})
+    tts.init_cnhuhbert_weights(state_dict=S.make_hubert_state_dict(seed=0))
+    wav = S.make_waveform(4 * 24000, 3, sr=24000).numpy()
+    p = str(tmp_path / "ref.wav")
+    _write_wav(p, wav, 24000)
+    tts.set_ref_audio(p)
+    ps = tts.prompt_cache["prompt_semantic"]
+    # 4 s + 0.3 s * 32000 / 16000 silence samples = 73600 samples at 16 kHz -> 229 HuBERT frames -> 114 codes
+    assert ps.dtype == torch.int64 and ps.dim() == 1 and ps.numel() == 114 and int(ps.max()) < 1024
+    spec = tts.prompt_cache["refer_spec"][0][0]
+    assert tuple(spec.shape) == (1, 1025, 200) and spec.dtype == torch.float16
+    short = str(tmp_path / "short.wav")
+    _write_wav(short, wav[: 2 * 24000], 24000)
+    with pytest.raises(OSError):
+        tts.set_ref_audio(short)
+    utt = S.make_utterances(2)
+    tts.prompt_cache["phones"] = utt["prompt_phones"]
+    tts.prompt_cache["bert_features"] = torch.zeros(1024, len(utt["prompt_phones"]))
+    segs = [{"phones": it["phones"], "bert_features": torch.zeros(1024, len(it["phones"])), "norm_text": it["norm_text"]}
+            for it in utt["items"]]
+    tts.configs.max_sec = 0.4
+    out = list(tts.run({"segments": segs, "batch_size": 2, "top_k": 1, "seed": 0}))
+    sr, audio = out[-1]
+    assert sr == 32000 and audio.dtype == np.int16 and audio.size == 2 * (20 * 1280 + int(32000 * 0.3))
