@@ -11,10 +11,16 @@ inputs are the tokenised segments (a few KB).  N > 1: one process per GPU (torch
 scattered from rank 0 and int16 fragments gathered back over RCCL inside the timed step
 (gsv/sharding.py); weak scaling (32 utterances per GPU).
 
-Prints ONE JSON line (rank 0).  `roofline` = the AR decode-attention kernel (HBM-bound, SURVEY.md
-section 8d): algorithmic KV bytes per launch / average launch time measured with HIP events inside the
-library on the engine's stream (gsv_t2s_time_step).  `cpu_baseline` = the oracle (CPU restatement,
-kind "port") on a bounded sample of the same workload on this box's host cores.
+`--total-utterances M` (BASELINE configs[2]): rank 0 submits M utterances per step, cut into batches of `--batch` that
+the ranks take from a work queue (strong scaling over the job, `"scaling": "strong"`).
+
+Prints ONE JSON line (rank 0).  `roofline` = the kernel with the largest share of GPU time: the persistent AR decode engine
+`t2s_mega_kernel` (one launch = all decode steps after step 0 of one batch; HBM-bound): algorithmic
+bytes of its steps / its duration from HIP events on the engine's stream (gsv_t2s_decode_info), measured on the LAST timed
+step; `roofline_step` / `roofline_prefill` / `roofline_generator` put the other stages against their bounds, `fp32` repeats a
+few steps with the parity dtype, `v3` times BASELINE configs[3] (one 934-frame chunk: 32 Euler steps of the DiT + BigVGAN),
+`cold_prompt` the reference-audio front-end (WAV -> HuBERT -> codes, spectrogram) that precedes a first utterance.
+`cpu_baseline` = the oracle (CPU restatement, kind "port") on a bounded sample of the same workload on this box's host cores.
 """
 from __future__ import annotations
 
@@ -91,6 +97,86 @@ def cpu_baseline(n_utt: int, tokens: int):
                       f"fp32 torch CPU oracle, AR + SoVITS decode"}
 
 
+def extra_fp32(dev, B, TOK, params, segs, prompt_args, steps=3):
+    """the same workload with the parity dtype (fp32 engines; the AR decode uses the launch-per-phase step)"""
+    from gsv import synthetic as S
+    tts = build_tts(dev, TOK, B, dtype_half=False)
+    tts.set_prompt_cache(*prompt_args[0], **prompt_args[1])
+    ts = []
+    for i in range(steps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _sr, _a in tts.run(dict(params, segments=segs)):
+            pass
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    best = statistics.median(ts[1:])
+    audio_s = tts.last_generated_tokens * 0.04
+    return {"value": round(audio_s / best, 2), "unit": "audio_s/s", "ms_per_step": round(1e3 * best, 2), "dtype": "f32",
+            "steps": steps, "note": "parity dtype: token ids bit-exact vs the reference (tests/test_t2s_gpu.py)"}
+
+
+def extra_v3(dev, n_steps=32, frames=934, prompt=468):
+    """BASELINE configs[3]: one 934-frame chunk with a 468-frame prompt through the full DiT (1024 x 22), 32 Euler steps, then
+    BigVGAN-v2 (24 kHz, x256) on the 466 new frames, fp16, random-init weights of the reference architecture."""
+    from gsv import synthetic as S
+    from gsv.BigVGAN.bigvgan import BigVGAN
+    from gsv.f5_tts.model.backbones.dit import DiT
+    from gsv.module.models import CFM
+    cfg = dict(S.DIT_V3_CONFIG)
+    dit = DiT(dim=cfg["dim"], depth=cfg["depth"], heads=cfg["heads"], dim_head=cfg["dim_head"], ff_mult=cfg["ff_mult"],
+              mel_dim=cfg["mel_dim"], text_dim=cfg["text_dim"], conv_layers=cfg["conv_layers"], device=str(dev), dtype=torch.float16)
+    dit.load_state_dict(S.make_dit_state_dict(cfg, seed=1))
+    cfm = CFM(100, dit)
+    voc = BigVGAN(dict(S.BIGVGAN_V2_24K_CONFIG), device=str(dev), dtype=torch.float16)
+    voc.load_state_dict(S.make_vocoder_state_dict(dict(S.BIGVGAN_V2_24K_CONFIG), seed=4))
+    mu = S.hash_symmetric("bench_mu", (1, frames, cfg["text_dim"]), 1.0, 1).to(dev)
+    pr = S.hash_symmetric("bench_prompt", (1, 100, prompt), 1.0, 1).to(dev)
+    cfm.inference(mu, None, pr, 2, seed=1)
+    new = frames - prompt
+    best_c, best_v = 1e9, 1e9
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        mel = cfm.inference(mu, None, pr, n_steps, seed=1)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        wav = voc(mel[:, :, prompt:].clamp(-12, 2))
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        best_c, best_v = min(best_c, t1 - t0), min(best_v, t2 - t1)
+    D, inner, FF = cfg["dim"], cfg["heads"] * cfg["dim_head"], cfg["dim"] * cfg["ff_mult"]
+    fl = cfg["depth"] * (2 * frames * (D * 3 * inner + inner * D + 2 * D * FF) + 4 * frames * frames * inner) \
+        + 2 * 2 * frames * D * (D // 16) * 31 + 2 * frames * (2 * 100 + cfg["text_dim"]) * D + 2 * frames * D * 100
+    audio_s = new * 256 / 24000.0
+    return {"workload": "BASELINE configs[3]: v3 flow-matching mel (DiT 1024 x 22, 934-frame chunk, 468-frame prompt, 32 Euler "
+                        "steps) + BigVGAN-v2 24 kHz x256 on the 466 new frames, fp16",
+            "cfm_ms_per_euler_step": round(1e3 * best_c / n_steps, 3), "cfm_ms": round(1e3 * best_c, 2),
+            "dit_tflops": round(fl * n_steps / best_c / 1e12, 1), "dit_frac_mfma": round(fl * n_steps / best_c / 2.5e15, 4),
+            "vocoder_ms": round(1e3 * best_v, 2), "vocoder_tflops": round(1.80e9 * new / best_v / 1e12, 1),
+            "audio_s_per_chunk": round(audio_s, 3), "value": round(audio_s / (best_c + best_v), 2), "unit": "audio_s/s",
+            "finite": bool(torch.isfinite(wav).all())}
+
+
+def extra_cold_prompt(tts, dev):
+    """reference-audio front-end before a first utterance: 8 s WAV -> 16 kHz -> HuBERT-base -> ssl_proj + VQ codes, and the
+    2048-point spectrogram at 32 kHz (reference TTS.py:751-819); random-init HuBERT weights"""
+    import tempfile
+    import wave as _wave
+    from gsv import synthetic as S
+    tts.init_cnhuhbert_weights(state_dict=S.make_hubert_state_dict(seed=0))
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "ref.wav")
+        x = S.make_waveform(8 * 32000, 1, sr=32000).numpy()
+        with _wave.open(p, "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(32000)
+            f.writeframes((x * 32767).astype("<i2").tobytes())
+        ts = []
+        for _ in range(4):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            tts.set_ref_audio(p)
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    return {"ms": round(1e3 * statistics.median(ts[1:]), 2), "first_call_ms": round(1e3 * ts[0], 2),
+            "what": "set_ref_audio: 8 s reference (host WAV read + resample, HuBERT-base 12 x 768, extract_latent, spectrogram)"}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -105,6 +191,9 @@ def main():
     ap.add_argument("--cpu-utts", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="parity dtype (not the benchmark configuration)")
+    ap.add_argument("--total-utterances", type=int, default=0,
+                    help="BASELINE configs[2]: utterances per step over the whole job, in batches of --batch (0 = --batch per GPU)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / v3 / cold-prompt sub-records")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile one extra step (host-side hot spots)")
     args = ap.parse_args()
 
@@ -127,9 +216,11 @@ def main():
     log(f"rank {rank}/{world}: building synthetic v2 checkpoints + engines")
     tts = build_tts(dev, TOK, B, dtype_half=not args.fp32)
     log("engines ready")
-    utt, segs_all = make_segments(B * world)
-    tts.set_prompt_cache(utt["prompt_semantic"], [S.make_refer_spec().to(dev)], phones=utt["prompt_phones"],
-                         bert_features=torch.zeros(1024, len(utt["prompt_phones"])), norm_text="x" * 40)
+    total = args.total_utterances if args.total_utterances > 0 else B * world
+    utt, segs_all = make_segments(total)
+    prompt_args = ((utt["prompt_semantic"], [S.make_refer_spec().to(dev)]),
+                   dict(phones=utt["prompt_phones"], bert_features=torch.zeros(1024, len(utt["prompt_phones"])), norm_text="x" * 40))
+    tts.set_prompt_cache(*prompt_args[0], **prompt_args[1])
     params = dict(batch_size=B, top_k=1, top_p=1.0, temperature=1.0, repetition_penalty=1.35, seed=0,
                   split_bucket=True, parallel_infer=True, fragment_interval=0.3)
     tok_count = [0]
@@ -153,7 +244,7 @@ def main():
     sh = ShardedSynthesizer(synth, dev)
 
     def step():
-        return sh.run(segs_all if rank == 0 else None)
+        return sh.run(segs_all if rank == 0 else None, batch_size=B if args.total_utterances > 0 else None)
 
     for i in range(args.warmup):
         step()
@@ -207,21 +298,32 @@ def main():
         # --- stage breakdown of the last step (reference prints the same four numbers, TTS.py:1320)
         t_text, t_batch, t_ar, t_dec = tts.last_timing
         vt_total, vt_gen = tts.vits_model.last_timing()
-        # --- roofline of the dominant AR kernel: decode attention streaming the KV arena
+        # --- roofline of the kernel with the largest share of GPU time (profiles/r02_bench_kernel_stats.csv): the persistent
+        # AR decode engine.  One launch covers every decode step after step 0 of the batch; its algorithmic bytes are the
+        # steps' weight + K/V bytes, its duration comes from HIP events on the engine stream.
+        mode, dec_ms, dec_steps = tts.t2s_model.decode_info()
         attn_ms, attn_bytes, step_bytes, layers_ms = tts.t2s_model.time_attention(iters=10)
-        ach = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
-        # HBM traffic per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE collected
-        # in separate rocprofv3 runs of this command, gfx950 2x read correction applied); valid for this workload
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
-        if os.path.exists(tj) and B == 32 and TOK == 100 and not args.fp32:
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "r02_mega_traffic.json")
+        if os.path.exists(tj) and B == 32 and TOK == 100 and not args.fp32 and mode == 1:
             traffic = json.load(open(tj)).get("traffic_bytes_per_launch")
-        roof = {"kernel": "decode_attn_kernel<f16,32>", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(attn_bytes), "avg_launch_us": round(attn_ms * 1e3, 2),
-                "note": "one launch = one layer's K+V arena for all rows at the end-of-run cache length; "
-                        "HIP events on the engine stream around 10x24 back-to-back launches over the 24 layers' "
-                        "distinct arenas (24 x 18 MB > Infinity Cache: every launch streams from HBM), rows forced active"}
+            traffic_src = "profiles/r02_mega_traffic.json (PMC passes of this command, replayed here)"
+        if mode == 1 and dec_steps > 0:
+            # K/V grows by one position per step: bytes at the end-of-run cache length minus the shortfall of earlier steps
+            kv_pos_bytes = attn_bytes / max(1, (80 + 100 + TOK)) if attn_bytes else 0      # one cached position, all rows, one layer
+            launch_bytes = dec_steps * step_bytes - 24 * kv_pos_bytes * dec_steps * (dec_steps - 1) / 2
+            ach = launch_bytes / (dec_ms * 1e-3) / 1e9
+            roof = {"kernel": "t2s_mega_kernel (persistent AR decode, %d steps per launch)" % dec_steps, "bound": "hbm",
+                    "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(launch_bytes),
+                    "avg_launch_us": round(dec_ms * 1e3, 1), "us_per_step": round(dec_ms * 1e3 / dec_steps, 1),
+                    "note": "algorithmic bytes = per step 152.4 MB of weights + K/V of every cached position of every row and "
+                            "layer (SURVEY 8d); HIP events on the engine stream around the one launch of the last timed step"}
+        else:
+            ach = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
+            roof = {"kernel": "decode_attn_kernel<f16,32> (launch-per-phase step)", "bound": "hbm", "achieved": round(ach, 1),
+                    "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None, "traffic_source": None,
+                    "algorithmic_bytes_per_launch": int(attn_bytes), "avg_launch_us": round(attn_ms * 1e3, 2)}
         # single-utterance latency (BASELINE configs[0] shape on the GPU): median of 5 one-sentence runs
         lat = []
         for _ in range(6):
@@ -235,12 +337,13 @@ def main():
         res = {
             "metric": "synthesised audio sec/sec (1/RTF), v2 pipeline", "value": round(audio_s / elapsed, 2),
             "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True,
+            "scaling": "strong" if args.total_utterances > 0 else "weak",
             "vs_baseline": None, "dtype": "f32" if args.fp32 else "f16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: v2 t2s+SoVITS, batch=32 fixed-length sentences per GPU "
                                    "(40+40 phonemes, 100 prompt tokens, 100 generated tokens = 4.0 s each), greedy, "
                                    "random-init v2 weights", "utterances_per_gpu": B, "tokens_per_utterance": TOK,
-                       "parallelism": f"utterance-sharded x{world}"},
+                       "total_utterances_per_step": total, "parallelism": f"utterance-sharded x{world}"},
             "p50_utterance_latency_ms": round(1e3 * statistics.median(times), 2),
             "step_ms": [round(1e3 * t, 1) for t in times],
             "p50_single_utterance_latency_ms": round(1e3 * lat_b1, 2),
@@ -248,11 +351,36 @@ def main():
             "stage_ms_last_step": {"to_batch": round(1e3 * t_batch, 2), "ar_t34": round(1e3 * t_ar, 2),
                                    "sovits_decode_t45": round(1e3 * t_dec, 2), "sovits_device": round(vt_total, 2),
                                    "generator_device": round(vt_gen, 2)},
-            "ar_step_algorithmic_bytes": int(step_bytes), "ar_step_layers_eager_ms": round(layers_ms, 4),
-            "ar_step_hbm_frac": round(step_bytes / (layers_ms * 1e-3) / 8e12, 4) if layers_ms > 0 else None,
+            "ar_decode_mode": "persistent engine" if mode == 1 else "launch per phase",
+            "ar_step_algorithmic_bytes": int(step_bytes),
+            "ar_step_ms": round(dec_ms / dec_steps, 4) if mode == 1 and dec_steps else round(layers_ms, 4),
+            "ar_step_launch_path_ms": round(layers_ms, 4),
+            "ar_step_hbm_frac": round(step_bytes / ((dec_ms / dec_steps if mode == 1 and dec_steps else layers_ms) * 1e-3) / 8e12, 4),
             "roofline": roof,
         }
+        # --- the other stages against their bounds: one decode step, the prefill, the HiFi-GAN generator
+        frames = B * TOK * 2
+        gen_flop, gen_bytes = 813.2e6 * frames, 3.1e6 * frames
+        res["roofline_step"] = {"bound": "hbm", "bytes": int(step_bytes), "ms": res["ar_step_ms"], "frac": res["ar_step_hbm_frac"]}
+        pf_flop = 2 * 76.18e6 * B * 180 + 4 * 180 * 180 * 512 * 24 * B
+        pf_ms = max(1e-3 * 0 + (1e3 * t_ar - (dec_ms if mode == 1 else layers_ms * (TOK - 1))), 1e-3)
+        res["roofline_prefill"] = {"bound": "mfma", "flop": pf_flop, "ms": round(pf_ms, 2), "tflops": round(pf_flop / pf_ms / 1e9, 1),
+                                   "frac": round(pf_flop / (pf_ms * 1e-3) / 2.5e15, 4),
+                                   "note": "AR stage wall time minus the decode launch: prefill + step 0 + host glue"}
+        res["roofline_generator"] = {"bound": "mfma+hbm", "flop": gen_flop, "ms": round(vt_gen, 2),
+                                     "tflops": round(gen_flop / (vt_gen * 1e-3) / 1e12, 1),
+                                     "frac_mfma": round(gen_flop / (vt_gen * 1e-3) / 2.5e15, 4),
+                                     "unfused_bytes": gen_bytes, "frac_hbm": round(gen_bytes / (vt_gen * 1e-3) / 8e12, 4)}
         log(f"gpu: {res['value']} audio_s/s, {res['ms_per_step']} ms/step; roofline {roof['achieved']} GB/s")
+        if not args.no_extras and world == 1 and args.total_utterances == 0 and not args.fp32:
+            log("extras: fp32 value, v3 record, cold prompt ...")
+            res["cold_prompt"] = extra_cold_prompt(tts, dev)
+            tts = None
+            sh = None
+            gc.collect(); torch.cuda.empty_cache()
+            res["fp32"] = extra_fp32(dev, B, TOK, params, segs_all[:B], prompt_args)
+            gc.collect(); torch.cuda.empty_cache()
+            res["v3"] = extra_v3(dev)
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (oracle) ...")
             res["cpu_baseline"] = cpu_baseline(args.cpu_utts, TOK)

@@ -1,16 +1,25 @@
-"""Utterance sharding across the GPUs of one node.
+"""Utterance sharding across the GPUs of one node (BASELINE configs[2] and [4]).
 
-The reference has no inference-side distribution.  After text segmentation every sentence is an
-independent job sharing one prompt, so the path shards by utterance: weights and the prompt cache
-are replicated, rank 0 scatters the tokenised segments, every rank runs AR -> decode locally with
-no steady-state communication, and rank 0 gathers the int16 fragments and restores submission
-order.  One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box,
-"gloo" in the CPU tests).  Payloads are KB (ids) and ~256 KB per 4 s utterance (int16), so plain
-point-to-point collectives are used: one broadcast out, one length all-gather + one padded gather in.
+The reference has no inference-side distribution.  After text segmentation every sentence is an independent job sharing one
+prompt, so the path shards by utterance: weights and the prompt cache are replicated, rank 0 broadcasts the tokenised
+segments (KB; BERT blocks only for zh text), the length-sorted segments are cut into BATCHES of `batch_size`, every rank
+synthesises whole batches locally with no steady-state communication, and each finished batch travels to rank 0 as int16
+fragments, point to point (xGMI: one link per peer into rank 0, no ring, no all-reduce).
+
+* Work queue: batches are handed out through an atomic counter in the process group's store (`store.add`), so a rank whose
+  rows hit EOS early simply takes the next batch ("next bucket goes to the first idle GPU"); without a store the
+  batches are dealt round-robin.
+* Streaming (configs[4], reference `return_fragment`, TTS.py:1321): `run_stream` yields on rank 0 as soon as the next batch
+  IN ORDER has arrived; rank 0 works on its own batches in between and only blocks on a receive when the queue is empty.
+* `run` (configs[1] / [2]) returns the whole job's audio in submission order.
+* A rank whose synthesis raises still sends its header (with an error flag) so that nobody waits for it; rank 0 re-raises.
+
+One process per GPU, `torch.distributed` (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests).
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence, Tuple
+import time
+from typing import Callable, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -20,9 +29,8 @@ from gsv.hostcopy import to_host
 
 
 def deal_contiguous(lengths: Sequence[int], world: int) -> List[List[int]]:
-    """Length-sort the items (stable) and give each rank one contiguous run of the sorted order, so a
-    rank's batches stay length-homogeneous (what to_batch's bucketing wants, reference
-    TTS_infer_pack/TTS.py:859-879).  Runs differ in size by at most one item."""
+    """Length-sort the items (stable) and give each rank one contiguous run of the sorted order; runs differ in size by at
+    most one item (kept for callers that want one share per rank)."""
     order = sorted(range(len(lengths)), key=lambda i: lengths[i])
     n = len(order)
     out, pos = [], 0
@@ -33,114 +41,216 @@ def deal_contiguous(lengths: Sequence[int], world: int) -> List[List[int]]:
     return out
 
 
-def pack_segments(segments: List[dict]) -> torch.Tensor:
-    """int32 wire format: [n, len_0 .. len_{n-1}, text_len_0 .. text_len_{n-1}, phones...].
-    BERT features are not shipped: the sharded path serves the non-zh case (all-zero features,
-    reference TextPreprocessor.py:216-220); zh callers shard after their own BERT pass."""
+def make_batches(lengths: Sequence[int], batch_size: int) -> List[List[int]]:
+    """Length-sorted (stable) order cut into runs of `batch_size`: batches stay length-homogeneous, which is what
+    to_batch's bucketing wants (reference TTS_infer_pack/TTS.py:859-879)."""
+    order = sorted(range(len(lengths)), key=lambda i: lengths[i])
+    return [order[i:i + batch_size] for i in range(0, len(order), batch_size)]
+
+
+def pack_segments(segments: List[dict], ship_bert: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """-> (int32 wire [n, has_bert_0.., len_0.., text_len_0.., phones...], float16 BERT blob [1024, sum of shipped columns] or
+    None).  All-zero BERT features (every non-zh segment, reference TextPreprocessor.py:216-220) are never shipped: None on the
+    receiving side is the engine's spelling of zeros.  Non-zero features are shipped, or refused loudly with ship_bert=False."""
     n = len(segments)
     lens = [len(s["phones"]) for s in segments]
     tl = [len(s["norm_text"]) for s in segments]
+    has, blobs = [], []
+    for s in segments:
+        b = s.get("bert_features")
+        nz = b is not None and bool(torch.as_tensor(b).any())
+        if nz and not ship_bert:
+            raise ValueError("pack_segments: a segment carries non-zero BERT features (zh text) and ship_bert=False would "
+                             "synthesise it as if they were zero")
+        if nz and tuple(b.shape) != (1024, len(s["phones"])):
+            raise ValueError(f"bert_features must be [1024, {len(s['phones'])}], got {tuple(b.shape)}")
+        has.append(int(nz))
+        if nz:
+            blobs.append(torch.as_tensor(b).to(torch.float16).cpu())
     flat = [p for s in segments for p in s["phones"]]
-    return torch.tensor([n] + lens + tl + flat, dtype=torch.int32)
+    wire = torch.tensor([n] + has + lens + tl + flat, dtype=torch.int32)
+    return wire, (torch.cat(blobs, 1).contiguous() if blobs else None)
 
 
-def unpack_segments(buf: torch.Tensor) -> List[dict]:
-    a = buf.cpu().tolist()
+def unpack_segments(wire: torch.Tensor, bert: Optional[torch.Tensor] = None) -> List[dict]:
+    a = wire.cpu().tolist()
     n = a[0]
-    lens, tl = a[1:1 + n], a[1 + n:1 + 2 * n]
-    out, o = [], 1 + 2 * n
+    has, lens, tl = a[1:1 + n], a[1 + n:1 + 2 * n], a[1 + 2 * n:1 + 3 * n]
+    out, o, bo = [], 1 + 3 * n, 0
     for i in range(n):
         ph = a[o:o + lens[i]]
         o += lens[i]
-        # all-zero BERT features by definition of this wire format: None is the engine's spelling of that (no 1024 x X
-        # zero block is allocated and scanned per segment and step)
-        out.append({"phones": ph, "bert_features": None, "norm_text": "x" * tl[i]})
+        bf = None
+        if has[i]:
+            bf = bert[:, bo:bo + lens[i]].float().cpu()
+            bo += lens[i]
+        out.append({"phones": ph, "bert_features": bf, "norm_text": "x" * tl[i]})
     return out
 
 
 class ShardedSynthesizer:
-    """`synth(segments) -> (int16 1-D numpy array or device tensor, per-fragment sample counts in the
-    order of `segments`)` is the local engine call (TTS wrapper in production, a stub in the gloo tests)."""
+    """`synth(segments) -> (int16 1-D numpy array or device tensor, per-fragment sample counts in the order of `segments`)`
+    is the local engine call (the TTS wrapper in production, a stub in the gloo tests)."""
 
-    def __init__(self, synth: Callable[[List[dict]], Tuple[torch.Tensor, List[int]]], device: torch.device,
-                 group=None):
+    def __init__(self, synth: Callable[[List[dict]], Tuple[torch.Tensor, List[int]]], device: torch.device, group=None,
+                 dynamic: bool = True):
         self.synth = synth
         self.device = device
         self.group = group
         self.on = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.on else 0
         self.world = dist.get_world_size(group) if self.on else 1
+        self.store = None
+        if self.on and dynamic and self.world > 1:
+            try:
+                from torch.distributed.distributed_c10d import _get_default_store
+                self.store = _get_default_store()
+            except Exception:
+                self.store = None
+        self._job = 0
+        self.last_synth_s = 0.0
+        self.last_owner: List[int] = []
 
-    def run(self, segments: Optional[List[dict]]) -> Optional[np.ndarray]:
-        """rank 0 passes all segments (others pass None); rank 0 returns the int16 audio of all
-        fragments in submission order, the other ranks return None."""
-        dev = self.device
-        # ---- scatter (one broadcast of the packed batch; ranks slice their share)
-        if self.world > 1:
-            hdr = torch.zeros(1, dtype=torch.int64, device=dev)
-            if self.rank == 0:
-                wire = pack_segments(segments).to(dev)
-                hdr[0] = wire.numel()
-            dist.broadcast(hdr, 0, group=self.group)
-            if self.rank != 0:
-                wire = torch.empty(int(hdr.item()), dtype=torch.int32, device=dev)
-            dist.broadcast(wire, 0, group=self.group)
-            segments = unpack_segments(wire)
-        shares = deal_contiguous([len(s["norm_text"]) for s in segments], self.world)
-        mine = shares[self.rank]
-        import time as _time
-        _t0 = _time.perf_counter()
-        audio, frag_lens = self.synth([segments[i] for i in mine]) if mine else (np.zeros(0, dtype=np.int16), [])
-        self.last_synth_s = _time.perf_counter() - _t0
+    # ---- scatter ---------------------------------------------------------------------------------------------------
+    def _broadcast_segments(self, segments: Optional[List[dict]], batch_size: int, ship_bert: bool):
         if self.world == 1:
-            a = to_host(audio) if torch.is_tensor(audio) else audio
-            assert a.dtype == np.int16 and sum(frag_lens) == a.size
-            return _reorder([a], [frag_lens], shares, len(segments))
-        if not torch.is_tensor(audio):
-            audio = torch.from_numpy(audio).to(dev)     # the gather works on device buffers (RCCL)
-        assert audio.dtype == torch.int16 and sum(frag_lens) == audio.numel()
-        # ---- gather (lengths, then one padded gather to rank 0)
-        n_local = torch.tensor([audio.numel()], dtype=torch.int64, device=dev)
-        all_n = [torch.zeros_like(n_local) for _ in range(self.world)]
-        dist.all_gather(all_n, n_local, group=self.group)
-        maxn = max(int(t.item()) for t in all_n)
-        # int16 samples travel as raw bytes: neither RCCL nor gloo has a 16-bit integer type
-        pad16 = torch.zeros(max(maxn, 1), dtype=torch.int16, device=dev)
-        pad16[: audio.numel()] = audio
-        pad = pad16.view(torch.uint8)
-        maxf = max(len(s) for s in shares)
-        fl = torch.zeros(max(maxf, 1), dtype=torch.int64, device=dev)
-        if frag_lens:
-            fl[: len(frag_lens)] = torch.tensor(frag_lens, dtype=torch.int64, device=dev)
+            return segments, batch_size
+        dev = self.device
+        hdr = torch.zeros(3, dtype=torch.int64, device=dev)
+        wire = bert = None
         if self.rank == 0:
-            bufs = [torch.zeros_like(pad) for _ in range(self.world)]
-            fbufs = [torch.zeros_like(fl) for _ in range(self.world)]
-            dist.gather(pad, bufs, dst=0, group=self.group)
-            dist.gather(fl, fbufs, dst=0, group=self.group)
-            # submission order is restored ON THE DEVICE (one concatenation of fragment views), then a single copy brings
-            # the result to the host: with 8 ranks the host-side concatenate of 70 MB was ~10 ms of rank 0's step
-            lens = [f[: len(s)].cpu().tolist() for f, s in zip(fbufs, shares)]
-            views = [b.view(torch.int16) for b in bufs]
-            frags: List[Optional[torch.Tensor]] = [None] * len(segments)
-            for v, ln_r, idxs in zip(views, lens, shares):
-                o = 0
-                for ln, i in zip(ln_r, idxs):
-                    frags[i] = v[o:o + ln]
-                    o += ln
-            keep = [f for f in frags if f is not None]
-            if not keep:
-                return np.zeros(0, dtype=np.int16)
-            return to_host(torch.cat(keep))
-        dist.gather(pad, None, dst=0, group=self.group)
-        dist.gather(fl, None, dst=0, group=self.group)
-        return None
+            wire, bert = pack_segments(segments, ship_bert)
+            hdr[0], hdr[1], hdr[2] = wire.numel(), (0 if bert is None else bert.shape[1]), batch_size
+        dist.broadcast(hdr, 0, group=self.group)
+        nw, nb, batch_size = (int(v) for v in hdr.tolist())
+        wire = wire.to(dev) if self.rank == 0 else torch.empty(nw, dtype=torch.int32, device=dev)
+        dist.broadcast(wire, 0, group=self.group)
+        if nb:
+            bert = bert.to(dev) if self.rank == 0 else torch.empty(1024, nb, dtype=torch.float16, device=dev)
+            dist.broadcast(bert, 0, group=self.group)
+        if self.rank != 0:
+            segments = unpack_segments(wire, bert if nb else None)
+        return segments, batch_size
 
+    # ---- work queue ------------------------------------------------------------------------------------------------
+    def _next_batch(self, job: int, nb: int, taken: List[int]) -> Optional[int]:
+        """index of the next unclaimed batch, or None.  Dynamic: atomic counter in the store; static: round-robin."""
+        if self.world == 1:
+            k = len(taken)
+            return k if k < nb else None
+        if self.store is not None:
+            k = int(self.store.add(f"gsv_shard_next_{job}", 1)) - 1
+            if k >= nb:
+                return None
+            self.store.set(f"gsv_shard_owner_{job}_{k}", str(self.rank))
+            return k
+        k = self.rank + self.world * len(taken)
+        return k if k < nb else None
 
-def _reorder(arrays: List[np.ndarray], frag_lens: List[List[int]], shares: List[List[int]], n: int) -> np.ndarray:
-    frags: List[Optional[np.ndarray]] = [None] * n
-    for arr, lens, idxs in zip(arrays, frag_lens, shares):
-        o = 0
-        for ln, i in zip(lens, idxs):
-            frags[i] = arr[o:o + ln]
-            o += ln
-    return np.concatenate([f for f in frags if f is not None]) if n else np.zeros(0, dtype=np.int16)
+    def _owner(self, job: int, k: int) -> int:
+        if self.store is not None:
+            return int(self.store.get(f"gsv_shard_owner_{job}_{k}"))          # blocks until the claimer has set it
+        return k % self.world
+
+    def _synth_batch(self, segs: List[dict]):
+        t0 = time.perf_counter()
+        try:
+            audio, frag_lens = self.synth(segs)
+            err = 0
+        except Exception as e:                                                 # noqa: BLE001 -- reported to rank 0, re-raised there
+            self._last_exc = e
+            audio, frag_lens, err = np.zeros(0, dtype=np.int16), [0] * len(segs), 1
+        self.last_synth_s += time.perf_counter() - t0
+        if not torch.is_tensor(audio):
+            audio = torch.from_numpy(np.ascontiguousarray(audio))
+        assert audio.dtype == torch.int16 and sum(frag_lens) == audio.numel() and len(frag_lens) == len(segs)
+        return audio, list(frag_lens), err
+
+    # ---- the job ---------------------------------------------------------------------------------------------------
+    def run_stream(self, segments: Optional[List[dict]], batch_size: int = 32, ship_bert: bool = True
+                   ) -> Iterator[Tuple[List[int], List[np.ndarray]]]:
+        """rank 0 passes all segments (the others None).  On rank 0 yields (segment indices of the batch, their int16 fragments)
+        batch by batch in the order of `make_batches`; on the other ranks yields nothing but must be iterated to the end."""
+        dev = self.device
+        self._job += 1
+        job = self._job
+        self.last_synth_s = 0.0
+        segments, batch_size = self._broadcast_segments(segments, batch_size, ship_bert)
+        batches = make_batches([len(s["norm_text"]) for s in segments], batch_size)
+        nb = len(batches)
+        done = {}                       # rank 0: batch index -> (audio host array, frag_lens) of its own batches
+        taken: List[int] = []
+        pending = []                    # other ranks: in-flight sends (buffers must outlive them)
+        self.last_owner = [-1] * nb
+
+        def work_one() -> bool:
+            k = self._next_batch(job, nb, taken)
+            if k is None:
+                return False
+            taken.append(k)
+            audio, frag_lens, err = self._synth_batch([segments[i] for i in batches[k]])
+            if self.rank == 0:
+                if err:
+                    raise self._last_exc
+                done[k] = (to_host(audio) if audio.is_cuda else audio.numpy(), frag_lens)
+            else:
+                # header: [batch, error, n_samples, frag lens...] then the samples as raw bytes (neither RCCL nor gloo has int16)
+                hdr = torch.tensor([k, err, audio.numel()] + frag_lens, dtype=torch.int64, device=dev)
+                pay = audio.to(dev).contiguous().view(torch.uint8) if audio.numel() else torch.zeros(2, dtype=torch.uint8, device=dev)
+                pending.append((hdr, pay, dist.isend(hdr, 0, group=self.group, tag=2 * k),
+                                dist.isend(pay, 0, group=self.group, tag=2 * k + 1)))
+            return True
+
+        if self.rank != 0:
+            while work_one():
+                pass
+            for _, _, h1, h2 in pending:
+                h1.wait(); h2.wait()
+            return
+        # rank 0: emit in order; do own work whenever the next batch in order is not there yet
+        more = True
+        for k in range(nb):
+            while k not in done:
+                if more:
+                    more = work_one()
+                    continue
+                owner = self._owner(job, k)
+                assert owner != 0, "a batch claimed by rank 0 is always in `done`"
+                hdr = torch.zeros(3 + len(batches[k]), dtype=torch.int64, device=dev)
+                dist.recv(hdr, owner, group=self.group, tag=2 * k)
+                h = hdr.tolist()
+                pay = torch.zeros(max(2 * h[2], 2), dtype=torch.uint8, device=dev)
+                dist.recv(pay, owner, group=self.group, tag=2 * k + 1)
+                if h[1]:
+                    raise RuntimeError(f"rank {owner} failed while synthesising batch {k}")
+                a = pay[: 2 * h[2]].view(torch.int16)
+                done[k] = (to_host(a) if a.is_cuda else a.numpy().copy(), [int(v) for v in h[3:]])
+                self.last_owner[k] = owner
+            if self.last_owner[k] < 0:
+                self.last_owner[k] = 0
+            audio, frag_lens = done.pop(k)
+            frags, o = [], 0
+            for ln in frag_lens:
+                frags.append(audio[o:o + ln])
+                o += ln
+            yield list(batches[k]), frags
+
+    def run(self, segments: Optional[List[dict]], batch_size: Optional[int] = None, ship_bert: bool = True) -> Optional[np.ndarray]:
+        """whole job: rank 0 returns the int16 audio of all fragments in submission order, the other ranks None.
+        `batch_size` None = one batch per rank (configs[1]'s weak-scaling step: 32 utterances per GPU)."""
+        if batch_size is None:
+            n = len(segments) if self.rank == 0 else 0
+            if self.world > 1:
+                t = torch.tensor([n], dtype=torch.int64, device=self.device)
+                dist.broadcast(t, 0, group=self.group)
+                n = int(t.item())
+            batch_size = max(1, -(-n // self.world))
+        n_total = len(segments) if self.rank == 0 else 0
+        out: List[Optional[np.ndarray]] = [None] * n_total
+        for idxs, frags in self.run_stream(segments, batch_size, ship_bert):
+            for i, f in zip(idxs, frags):
+                out[i] = f
+        if self.rank != 0:
+            return None
+        keep = [f for f in out if f is not None]
+        return np.concatenate(keep) if keep else np.zeros(0, dtype=np.int16)

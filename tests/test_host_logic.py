@@ -61,64 +61,136 @@ def test_recovery_order_and_postprocess_scaling():
     assert out[1] == np.array([-32768.0]).astype(np.int16)[0]
 
 
-def test_deal_contiguous_and_wire_format_roundtrip():
+def test_deal_contiguous_batches_and_wire_format_roundtrip():
     lens = [5, 1, 9, 3, 7, 2, 8]
     shares = sharding.deal_contiguous(lens, 3)
     assert sorted(sum(shares, [])) == list(range(7))
     assert [len(s) for s in shares] == [3, 2, 2]
     assert [lens[i] for i in shares[0]] == [1, 2, 3]          # shortest run on rank 0
+    assert sharding.make_batches(lens, 3) == [[1, 5, 3], [0, 4, 6], [2]]      # length-sorted runs of 3
+    # BASELINE configs[2]: 1024 utterances -> 32 batches of 32
+    assert [len(b) for b in sharding.make_batches([40] * 1024, 32)] == [32] * 32
     segs = [_seg(n, n + 1) for n in (3, 1, 4)]
-    back = sharding.unpack_segments(sharding.pack_segments(segs))
+    wire, bert = sharding.pack_segments(segs)
+    assert bert is None                                         # all-zero BERT features are never shipped
+    back = sharding.unpack_segments(wire, bert)
     assert [b["phones"] for b in back] == [s["phones"] for s in segs]
-    assert [len(b["norm_text"]) for b in back] == [4, 2, 5]
-    assert sharding.unpack_segments(sharding.pack_segments([])) == []
+    assert [len(b["norm_text"]) for b in back] == [4, 2, 5] and all(b["bert_features"] is None for b in back)
+    assert sharding.unpack_segments(*sharding.pack_segments([])) == []
+    # zh segments: non-zero features travel (fp16) -- or are refused loudly, never dropped
+    segs[1]["bert_features"] = torch.arange(1024, dtype=torch.float32).unsqueeze(1) / 1024
+    wire, bert = sharding.pack_segments(segs)
+    assert tuple(bert.shape) == (1024, 1)
+    back = sharding.unpack_segments(wire, bert)
+    assert back[0]["bert_features"] is None and torch.allclose(back[1]["bert_features"], segs[1]["bert_features"], atol=1e-3)
+    with pytest.raises(ValueError):
+        sharding.pack_segments(segs, ship_bert=False)
 
 
 def _stub_synth(segments):
-    """fake engine: fragment i = int16 ramp of length 10*len(phones) filled with phones[0]"""
-    frags = [torch.full((10 * len(s["phones"]),), s["phones"][0] if s["phones"] else 0, dtype=torch.int16) for s in segments]
+    """fake engine: fragment i = int16 ramp of length 10*len(phones) filled with phones[0] (+ 100 when BERT features arrived)"""
+    frags = [torch.full((10 * len(s["phones"]),), (s["phones"][0] if s["phones"] else 0) + (100 if s["bert_features"] is not None and bool(s["bert_features"].any()) else 0),
+                        dtype=torch.int16) for s in segments]
     return (torch.cat(frags) if frags else torch.zeros(0, dtype=torch.int16)), [int(f.numel()) for f in frags]
 
 
 def test_sharded_synthesizer_single_process_restores_order():
     segs = [{"phones": [i + 1] * n, "bert_features": torch.zeros(1024, n), "norm_text": "x" * n} for i, n in enumerate((4, 1, 3))]
-    out = sharding.ShardedSynthesizer(_stub_synth, torch.device("cpu")).run(segs)
-    assert out.tolist() == [1] * 40 + [2] * 10 + [3] * 30
+    sh = sharding.ShardedSynthesizer(_stub_synth, torch.device("cpu"))
+    assert sh.run(segs).tolist() == [1] * 40 + [2] * 10 + [3] * 30
+    got = list(sh.run_stream(segs, batch_size=2))                       # batches in length order: [1, 2], then [0]
+    assert [idx for idx, _ in got] == [[1, 2], [0]]
+    assert [f.tolist() for f in got[0][1]] == [[2] * 10, [3] * 30]
 
 
-def _gloo_worker(rank, world, port, q):
+def _gloo_worker(rank, world, port, q, mode):
     import os
+    import time
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         segs = None
+        lens = (4, 1, 3, 6, 2, 5, 7)
         if rank == 0:
-            segs = [{"phones": [i + 1] * n, "bert_features": torch.zeros(1024, n), "norm_text": "x" * n}
-                    for i, n in enumerate((4, 1, 3, 6, 2))]
-        out = sharding.ShardedSynthesizer(_stub_synth, torch.device("cpu")).run(segs)
-        q.put((rank, None if out is None else out.tolist()))
+            segs = [{"phones": [i + 1] * n, "bert_features": torch.zeros(1024, n), "norm_text": "x" * n} for i, n in enumerate(lens)]
+            if mode == "bert":
+                segs[2]["bert_features"] = torch.ones(1024, 3)
+        calls = []
+
+        def synth(segments):
+            calls.append(len(segments))
+            if mode == "slow_rank1" and rank == 1:
+                time.sleep(0.4)                                     # uneven work: the queue must hand the rest to the idle ranks
+            if mode == "fail" and rank == world - 1:
+                raise RuntimeError("engine failure on the last rank")
+            return _stub_synth(segments)
+        sh = sharding.ShardedSynthesizer(synth, torch.device("cpu"), dynamic=mode not in ("static", "fail"))   # static dealing: the failing rank is sure to own a batch
+        if mode in ("stream", "slow_rank1"):
+            order, flat = [], []
+            for idxs, frags in sh.run_stream(segs, batch_size=2):
+                order.append(idxs)
+                flat.append([f.tolist() for f in frags])
+            q.put((rank, {"order": order, "flat": flat, "calls": calls, "owner": list(sh.last_owner)}))
+        else:
+            try:
+                out = sh.run(segs, batch_size=2 if mode != "weak" else None)
+                q.put((rank, {"out": None if out is None else out.tolist(), "calls": calls}))
+            except RuntimeError as e:
+                q.put((rank, {"error": str(e), "calls": calls}))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_synthesizer_gloo_world(world):
-    """N > 1 path on CPU: scatter (broadcast + slice), local synthesis, padded gather, order restore."""
+def _run_gloo(world, mode, salt):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + world * 7 + (os_getpid() % 200)
-    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + world * 7 + salt + (os_getpid() % 200)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    exp = [1] * 40 + [2] * 10 + [3] * 30 + [4] * 60 + [5] * 20
-    assert res[0] == exp
-    assert all(res[r] is None for r in range(1, world))
+    return res
+
+
+EXP = [1] * 40 + [2] * 10 + [3] * 30 + [4] * 60 + [5] * 20 + [6] * 50 + [7] * 70
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mode", ["dynamic", "static", "weak"])
+def test_sharded_synthesizer_gloo_world(world, mode):
+    """N > 1 on CPU: broadcast, batches from the work queue (store counter) or round-robin, point-to-point return of each
+    batch, submission order restored; `weak` = one batch per rank (the benchmark's configs[1] step)."""
+    res = _run_gloo(world, mode, {"dynamic": 0, "static": 11, "weak": 23}[mode])
+    assert res[0]["out"] == EXP
+    assert all(res[r]["out"] is None for r in range(1, world))
+    assert sum(sum(res[r]["calls"]) for r in range(world)) == 7        # every utterance synthesised exactly once
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_streaming_yields_batches_in_order_with_work_queue(world):
+    """BASELINE configs[4] semantics: rank 0 yields batch after batch in order (return_fragment, TTS.py:1321) while a slow
+    rank holds one batch; the other ranks drain the queue meanwhile."""
+    res = _run_gloo(world, "slow_rank1", 37)
+    r0 = res[0]
+    assert r0["order"] == [[1, 4], [2, 0], [5, 3], [6]]                # make_batches order of lens (4,1,3,6,2,5,7), size 2
+    flat = sum(r0["flat"], [])
+    assert flat == [[2] * 10, [5] * 20, [3] * 30, [1] * 40, [6] * 50, [4] * 60, [7] * 70]
+    assert all(0 <= o < world for o in r0["owner"])                     # who served which batch is the queue's business
+    assert sum(len(res[r]["calls"]) for r in range(world)) == 4
+    assert all(res[r]["order"] == [] for r in range(1, world))
+
+
+def test_sharded_bert_features_are_shipped_and_failures_propagate():
+    res = _run_gloo(2, "bert", 51)
+    out = res[0]["out"]
+    assert out[50:80] == [103] * 30 and out[:40] == [1] * 40           # the zh segment arrived WITH its features
+    res = _run_gloo(3, "fail", 63)
+    assert "error" in res[0] and "failed" in res[0]["error"]           # rank 0 raises instead of waiting for ever
 
 
 def os_getpid():
