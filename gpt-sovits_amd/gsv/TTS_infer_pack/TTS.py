@@ -58,28 +58,60 @@ def set_seed(seed: int) -> int:
 
 
 class TTS_Config:
-    """Subset of the reference's TTS_Config (TTS.py:217-410) the hot path reads.  `configs` is a dict
-    with the reference's keys (device, is_half, version, t2s_weights_path, vits_weights_path); weight
-    paths may also be replaced by in-memory checkpoints via TTS.init_*_weights(state=...)."""
-    v1_languages = ["auto", "auto_yue", "en", "zh", "ja", "all_zh", "all_ja"]
+    """The reference's TTS_Config surface (TTS.py:217-410): `configs` is a dict (the sections "v1" ... "v2ProPlus" and / or
+    "custom", or directly the custom section's keys), a YAML file path, or None (defaults).  Differences, all forced by the
+    platform: the default device is the GPU ("cuda:0", half precision on) instead of "cpu" -- there is no CPU path -- and a
+    weights path that does not exist is kept as given (the engines take in-memory checkpoints too, `TTS.init_*_weights(state=)`)
+    instead of silently falling back to the pretrained-model default.  `max_batch` / `max_seq` size the AR engine's K/V arena."""
+    default_configs = {
+        v: {"device": "cuda:0", "is_half": True, "version": v, "t2s_weights_path": "GPT_SoVITS/pretrained_models/" + t,
+            "vits_weights_path": "GPT_SoVITS/pretrained_models/" + s_,
+            "cnhuhbert_base_path": "GPT_SoVITS/pretrained_models/chinese-hubert-base",
+            "bert_base_path": "GPT_SoVITS/pretrained_models/chinese-roberta-wwm-ext-large"}
+        for v, t, s_ in (("v1", "s1bert25hz-2kh-longer-epoch=68e-step=50232.ckpt", "s2G488k.pth"),
+                         ("v2", "gsv-v2final-pretrained/s1bert25hz-5kh-longer-epoch=12-step=369668.ckpt", "gsv-v2final-pretrained/s2G2333k.pth"),
+                         ("v3", "s1v3.ckpt", "s2Gv3.pth"), ("v4", "s1v3.ckpt", "gsv-v4-pretrained/s2Gv4.pth"),
+                         ("v2Pro", "s1v3.ckpt", "v2Pro/s2Gv2Pro.pth"), ("v2ProPlus", "s1v3.ckpt", "v2Pro/s2Gv2ProPlus.pth"))
+    }
+    v1_languages = ["auto", "en", "zh", "ja", "all_zh", "all_ja"]
     v2_languages = ["auto", "auto_yue", "en", "zh", "ja", "yue", "ko", "all_zh", "all_ja", "all_yue", "all_ko"]
+    _KEYS = ("device", "is_half", "version", "t2s_weights_path", "vits_weights_path", "bert_base_path", "cnhuhbert_base_path")
 
-    def __init__(self, configs: Optional[dict] = None):
-        configs = dict(configs or {})
-        if "custom" in configs:
-            configs = dict(configs["custom"])
-        self.device = torch.device(configs.get("device", "cuda:0"))
-        self.is_half = bool(configs.get("is_half", True))
-        self.version = configs.get("version", "v2")
+    def __init__(self, configs=None):
+        from copy import deepcopy
+        self.configs_path = os.path.join("GPT_SoVITS", "configs", "tts_infer.yaml")
+        if configs in ["", None]:
+            configs = {}
+        if isinstance(configs, str):
+            self.configs_path = configs
+            configs = self._load_configs(configs)
+        if not isinstance(configs, dict):
+            raise TypeError("configs must be a dict, a YAML path or None")
+        sections = deepcopy(self.default_configs)
+        if any(k in configs for k in list(self.default_configs) + ["custom"]):
+            sections.update(deepcopy(configs))
+            custom = sections.get("custom", sections["v2"])
+        else:                                   # the custom section's keys given directly
+            if configs.get("version", "v2") not in sections:
+                raise NotImplementedError(f"version {configs.get('version')} is not one of v1, v2, v2Pro, v2ProPlus, v3, v4")
+            custom = dict(sections[configs.get("version", "v2")], **configs)
+        self.default_configs = sections
+        self.configs = dict(custom)
+        self.device = torch.device(custom.get("device", "cuda:0"))
+        self.is_half = bool(custom.get("is_half", True))
+        self.version = custom.get("version", "v2")
         if self.version not in ("v1", "v2", "v2Pro", "v2ProPlus", "v3", "v4"):
             raise NotImplementedError(f"version {self.version} is not one of v1, v2, v2Pro, v2ProPlus, v3, v4")
-        self.t2s_weights_path = configs.get("t2s_weights_path")
-        self.vits_weights_path = configs.get("vits_weights_path")
-        self.max_batch = int(configs.get("max_batch", 32))
+        self.t2s_weights_path = custom.get("t2s_weights_path")
+        self.vits_weights_path = custom.get("vits_weights_path")
+        self.bert_base_path = custom.get("bert_base_path")
+        self.cnhuhbert_base_path = custom.get("cnhuhbert_base_path")
+        self.max_batch = int(custom.get("max_batch", 32))
         # K/V arena positions per row: the reference's 1500-step loop (t2s_model.py:694) + a 10 s prompt (250 tokens)
         # + phonemes of prompt and text; 2560 x 32 rows x 24 layers is 4 GB of fp16 K/V
-        self.max_seq = int(configs.get("max_seq", 2560))
+        self.max_seq = int(custom.get("max_seq", 2560))
         self.use_vocoder = self.version in ("v3", "v4")     # TTS.py:519-521
+        self.languages = self.v1_languages if self.version == "v1" else self.v2_languages
         self.max_sec = None
         self.hz: int = 50
         self.semantic_frame_rate: str = "25hz"
@@ -89,7 +121,54 @@ class TTS_Config:
         self.hop_length: int = 640
         self.win_length: int = 2048
         self.n_speakers: int = 300
+        self.update_configs()
+
+    def _load_configs(self, configs_path: str) -> dict:
+        import yaml
+        if not os.path.exists(configs_path):
+            self.configs = None
+            self.save_configs(configs_path)          # reference :361-366: a missing file is created from the defaults
+        with open(configs_path, "r", encoding="utf-8") as f:
+            return yaml.load(f, Loader=yaml.SafeLoader) or {}
+
+    def save_configs(self, configs_path: Optional[str] = None) -> None:
+        import yaml
+        from copy import deepcopy
+        configs = deepcopy(self.default_configs)
+        if getattr(self, "configs", None) is not None:
+            configs["custom"] = self.update_configs()
+        configs_path = configs_path or self.configs_path
+        d = os.path.dirname(configs_path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        with open(configs_path, "w") as f:
+            yaml.dump(configs, f)
+
+    def update_configs(self) -> dict:
+        self.config = {"device": str(self.device), "is_half": self.is_half, "version": self.version,
+                       "t2s_weights_path": self.t2s_weights_path, "vits_weights_path": self.vits_weights_path,
+                       "bert_base_path": self.bert_base_path, "cnhuhbert_base_path": self.cnhuhbert_base_path}
+        return self.config
+
+    def update_version(self, version: str) -> None:
+        self.version = version
+        self.use_vocoder = version in ("v3", "v4")
         self.languages = self.v1_languages if self.version == "v1" else self.v2_languages
+
+    def __str__(self):
+        self.configs = self.update_configs()
+        string = "TTS Config".center(100, "-") + "\n"
+        for k, v in self.configs.items():
+            string += f"{str(k).ljust(20)}: {str(v)}\n"
+        return string + "-" * 100 + "\n"
+
+    __repr__ = __str__
+
+    def __hash__(self):
+        return hash(self.configs_path)
+
+    def __eq__(self, other):
+        return isinstance(other, TTS_Config) and self.configs_path == other.configs_path
 
     @property
     def precision(self):
@@ -213,6 +292,55 @@ class TTS:
         self.prompt_cache["bert_features"] = bert_features
         self.prompt_cache["norm_text"] = norm_text
 
+    # ---- device / precision (reference TTS.py:677-735) -----------------------------------------------------------
+    def enable_half_precision(self, enable: bool = True, save: bool = True):
+        """reference TTS.py:677-713: switch every model between fp16 and fp32.  The HIP engines hold their weights in the
+        compute dtype, so the models are rebuilt from the retained checkpoints."""
+        if str(self.configs.device) == "cpu" and enable:
+            raise RuntimeError("half precision needs the GPU")
+        if bool(enable) == self.configs.is_half:
+            return
+        self.configs.is_half = bool(enable)
+        self.precision = self.configs.precision
+        if save:
+            self.configs.save_configs()
+        self._rebuild_models()
+
+    def set_device(self, device, save: bool = True):
+        """reference TTS.py:715-735: move every model to `device` (another MI355X: there is no CPU path)."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("gsv engines run on an MI355X (cuda/HIP device) only; there is no CPU path")
+        self.configs.device = device
+        if save:
+            self.configs.save_configs()
+        self._rebuild_models()
+
+    def _rebuild_models(self):
+        if self._t2s_state is not None:
+            self.t2s_model = None
+            self.init_t2s_weights(self.configs.t2s_weights_path, state=self._t2s_state)
+        if self._vits_state is not None:
+            self.vits_model = None
+            self.init_vits_weights(self.configs.vits_weights_path, state=self._vits_state)
+        if getattr(self, "_hubert_state", None) is not None:
+            self.init_cnhuhbert_weights(state_dict=self._hubert_state)
+        if getattr(self, "_bert_state", None) is not None:
+            self.init_bert_weights(state_dict=self._bert_state[0], vocab=self._bert_state[1])
+        for k in ("prompt_semantic",):
+            if self.prompt_cache.get(k) is not None:
+                self.prompt_cache[k] = self.prompt_cache[k].to(self.configs.device)
+        self.prompt_cache["refer_spec"] = [(sp.to(self.configs.device), a) for sp, a in self.prompt_cache["refer_spec"]]
+
+    def init_bert_weights(self, base_path: Optional[str] = None, state_dict: Optional[dict] = None, vocab=None):
+        """chinese-roberta-wwm-ext-large for zh text (reference TTS.py:472-482, TextPreprocessor.py:191-204): hidden_states[-3]
+        per character.  `state_dict` / `vocab` (list of tokens) replace the directory for tests."""
+        from ..feature_extractor.bert import BertFeature
+        self.bert_model = BertFeature(base_path, device=self.configs.device, state_dict=state_dict, vocab=vocab)
+        self._bert_state = (state_dict, vocab) if state_dict is not None else None
+        self.text_preprocessor.bert_fn = self.bert_model
+        self.configs.bert_base_path = base_path
+
     # ---- reference-audio front-end (reference TTS.py:462-482, 737-819) -------------------------------------------
     def init_cnhuhbert_weights(self, base_path: Optional[str] = None, state_dict: Optional[dict] = None):
         """HuBERT-base content encoder (reference TTS.py:462-470; feature_extractor/cnhubert.py).  `state_dict` = a
@@ -220,6 +348,8 @@ class TTS:
         model.safetensors."""
         from ..feature_extractor.cnhubert import CNHubert
         self.cnhuhbert_model = CNHubert(base_path, device=self.configs.device, dtype=torch.float16, state_dict=state_dict)
+        self._hubert_state = state_dict
+        self.configs.cnhuhbert_base_path = base_path
 
     def set_ref_audio(self, ref_audio_path: str):
         """reference TTS.py:737-747: prompt semantic tokens (HuBERT -> ssl_proj -> VQ) and the reference spectrogram."""

@@ -572,3 +572,34 @@ def make_waveform(n: int, seed: int = 0, sr: int = 16000) -> torch.Tensor:
     y = sum(np.sin(k * ph + 0.3 * k) / k for k in range(1, 9)) * (0.6 + 0.4 * np.sin(2 * np.pi * 3.1 * t))
     y = 0.25 * y / np.abs(y).max() + 0.05 * (hash_uniform("wave_noise", n, seed).astype(np.float64) - 0.5)
     return torch.from_numpy(y.astype(np.float32))
+
+
+# --------------------------------------------------------------------------
+# BERT-large (reference TTS.py:472-482: chinese-roberta-wwm-ext-large, a transformers BertForMaskedLM)
+# --------------------------------------------------------------------------
+BERT_TEST_VOCAB = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list("，。！？、：；你好我是小明今天气不错们一起去公园散步吧的了在有人这中大为上个国和地到以说时要就出会可也") + list("abcxyz0123456789")
+
+
+def make_bert_state_dict(seed: int = 0, layers: int = 24, hidden: int = 1024, ffn: int = 4096, vocab: int = len(BERT_TEST_VOCAB),
+                         positions: int = 512) -> "OrderedDict[str, torch.Tensor]":
+    """fp32 state dict with transformers.BertModel's key names."""
+    sd = OrderedDict()
+    sd["embeddings.word_embeddings.weight"] = hash_symmetric("bert.word", (vocab, hidden), 1.0, seed)
+    sd["embeddings.position_embeddings.weight"] = hash_symmetric("bert.pos", (positions, hidden), 0.5, seed)
+    sd["embeddings.token_type_embeddings.weight"] = hash_symmetric("bert.type", (2, hidden), 0.5, seed)
+    sd["embeddings.LayerNorm.weight"] = 1.0 + hash_symmetric("bert.embln.w", (hidden,), 0.1, seed)
+    sd["embeddings.LayerNorm.bias"] = _b("bert.embln.b", hidden, 0.1, seed)
+    for i in range(layers):
+        p = f"encoder.layer.{i}."
+        for nm in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            sd[p + nm + ".weight"] = _w(p + nm + ".w", (hidden, hidden), hidden, 1.0, seed)
+            sd[p + nm + ".bias"] = _b(p + nm + ".b", hidden, 0.05, seed)
+        sd[p + "attention.output.LayerNorm.weight"] = 1.0 + hash_symmetric(p + "ln1.w", (hidden,), 0.1, seed)
+        sd[p + "attention.output.LayerNorm.bias"] = _b(p + "ln1.b", hidden, 0.1, seed)
+        sd[p + "intermediate.dense.weight"] = _w(p + "f1.w", (ffn, hidden), hidden, 1.0, seed)
+        sd[p + "intermediate.dense.bias"] = _b(p + "f1.b", ffn, 0.05, seed)
+        sd[p + "output.dense.weight"] = _w(p + "f2.w", (hidden, ffn), ffn, 1.0, seed)
+        sd[p + "output.dense.bias"] = _b(p + "f2.b", hidden, 0.05, seed)
+        sd[p + "output.LayerNorm.weight"] = 1.0 + hash_symmetric(p + "ln2.w", (hidden,), 0.1, seed)
+        sd[p + "output.LayerNorm.bias"] = _b(p + "ln2.b", hidden, 0.1, seed)
+    return sd

@@ -2,6 +2,8 @@
 
   tests/golden/spec_*.npz     the reference's own `spectrogram_torch` (GPT_SoVITS/module/mel_processing.py:40-74, pure torch: it
                               imports here with oracle/ref_import's librosa stub) on seeded waveforms
+  tests/golden/bert_large.npz `transformers.BertModel` (BERT-large shape = chinese-roberta-wwm-ext-large's encoder) on
+                              gsv.synthetic.make_bert_state_dict weights: hidden_states[-3][1:-1] of a 25-character string
   tests/golden/hubert_base.npz `transformers.HubertModel(HubertConfig())` -- the class the reference's CNHubert wraps
                               (feature_extractor/cnhubert.py:22-37) -- with gsv.synthetic.make_hubert_state_dict weights on a
                               seeded 1.3 s waveform: last_hidden_state (fp16) and a few intermediate checksums.
@@ -24,6 +26,7 @@ from oracle import ref_import  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 SPEC_CASES = {"spec_32k_half_s": (16000, 0), "spec_32k_ragged": (22001, 1), "spec_short": (1500, 2)}
+BERT_TEXT = "你好，我是小明。今天天气不错，我们一起去公园散步吧！"
 HUBERT_N = 20800          # 1.3 s at 16 kHz -> 64 frames
 
 
@@ -44,6 +47,20 @@ def main():
                         conv_features_rms=np.float32(feats.pow(2).mean().sqrt().item()),
                         layer_rms=np.array([x.pow(2).mean().sqrt().item() for x in out["hidden_states"]], dtype=np.float32))
     print("hubert", tuple(h.shape), "rms", float(h.pow(2).mean().sqrt()))
+    # ---- BERT-large: hidden_states[-3][1:-1] exactly as TextPreprocessor.get_bert_feature takes it (:191-198)
+    from transformers import BertConfig, BertModel
+    bcfg = BertConfig(vocab_size=len(S.BERT_TEST_VOCAB), hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                      intermediate_size=4096, max_position_embeddings=512)
+    bm = BertModel(bcfg, add_pooling_layer=False).eval()
+    miss = bm.load_state_dict(S.make_bert_state_dict(seed=0), strict=False)
+    assert not miss.unexpected_keys and all("position_ids" in k for k in miss.missing_keys), miss
+    tok = {t: i for i, t in enumerate(S.BERT_TEST_VOCAB)}
+    ids = [tok["[CLS]"]] + [tok.get(ch, tok["[UNK]"]) for ch in BERT_TEXT] + [tok["[SEP]"]]
+    with torch.no_grad():
+        res = bm(input_ids=torch.tensor([ids]), output_hidden_states=True)
+    feat = torch.cat(res["hidden_states"][-3:-2], -1)[0][1:-1]
+    np.savez_compressed(os.path.join(GOLD, "bert_large.npz"), feature=feat.numpy().astype(np.float16))
+    print("bert", tuple(feat.shape), "rms", float(feat.pow(2).mean().sqrt()))
     # the reference's module needs oracle/ref_import's third-party stubs, which would break the transformers import above
     ref_import.setup()
     from module.mel_processing import spectrogram_torch

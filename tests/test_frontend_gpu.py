@@ -93,3 +93,54 @@ def test_set_ref_audio_end_to_end(tmp_path):
     out = list(tts.run({"segments": segs, "batch_size": 2, "top_k": 1, "seed": 0}))
     sr, audio = out[-1]
     assert sr == 32000 and audio.dtype == np.int16 and audio.size == 2 * (20 * 1280 + int(32000 * 0.3))
+
+
+def test_bert_feature_matches_transformers_model():
+    """zh BERT features: fp16 engine (22 of 24 BERT-large layers) vs transformers.BertModel fp32 hidden_states[-3][1:-1] on the
+    same synthetic weights and a 26-character string (rms 1.0): relative rms <= 1 %, max-abs <= 5e-2; one row per character,
+    unknown characters map to [UNK], more than 510 characters are refused."""
+    from gsv import synthetic as S
+    from gsv.feature_extractor.bert import BertFeature
+    text = "你好，我是小明。今天天气不错，我们一起去公园散步吧！"
+    ref = load_golden("bert_large")["feature"].astype(np.float32)
+    bf = BertFeature(device=DEV, state_dict=S.make_bert_state_dict(seed=0), vocab=S.BERT_TEST_VOCAB)
+    out = bf(text)
+    assert tuple(out.shape) == (len(text), 1024) == ref.shape
+    o = out.cpu().numpy()
+    rel = np.sqrt(((o - ref) ** 2).mean() / (ref ** 2).mean())
+    err = np.abs(o - ref).max()
+    print(f"[frontend] BERT hidden_states[-3]: relative rms {rel:.3e}, max-abs {err:.3e}")
+    assert rel <= 1e-2 and err <= 5e-2
+    assert bf.tokenize("你?") == [2, S.BERT_TEST_VOCAB.index("你"), 1, 3]          # '?' (ASCII) is not in the test vocabulary
+    with pytest.raises(ValueError):
+        bf("好" * 511)
+
+
+def test_zh_text_through_preprocessor_with_bert_engine():
+    """the plug-in seam end to end: TextPreprocessor (zh) -> BertFeature -> phone-level features [1024, n_phones]"""
+    from gsv import synthetic as S
+    from gsv.feature_extractor.bert import BertFeature
+    from gsv.text import cleaner
+    from gsv.TTS_infer_pack.TextPreprocessor import TextPreprocessor
+
+    class Zh:
+        def text_normalize(self, t):
+            return t
+
+        def g2p(self, norm):
+            ph, w2p = [], []
+            for ch in norm:
+                if ch in "，。！？":
+                    ph.append({"，": ",", "。": ".", "！": "!", "？": "?"}[ch]); w2p.append(1)
+                else:
+                    ph += ["n", "i3"]; w2p.append(2)
+            return ph, w2p
+    cleaner.register_g2p("zh", Zh())
+    bf = BertFeature(device=DEV, state_dict=S.make_bert_state_dict(seed=0, layers=22), vocab=S.BERT_TEST_VOCAB)
+    tp = TextPreprocessor(bert_fn=bf)
+    segs = tp.preprocess("你好，我是小明。今天天气不错！", "all_zh", "cut5", "v2")
+    assert [sg["norm_text"] for sg in segs] == ["你好，我是小明。", "今天天气不错！"]       # "你好，" (< 5 characters) merges forward
+    for sg in segs:
+        assert sg["bert_features"].shape == (1024, len(sg["phones"])) and bool(sg["bert_features"].any())
+    f = segs[0]["bert_features"]
+    assert torch.equal(f[:, 0], f[:, 1]) and not torch.equal(f[:, 1], f[:, 2])      # two phones of one character share its vector

@@ -1,6 +1,7 @@
 """CPU: host-side pipeline logic restated from the reference (TTS.to_batch bucketing, recovery_order,
 audio_postprocess scaling, fragment split arithmetic, early-stop semantics) with hand-computed
 expectations, plus the utterance sharding wire format (SURVEY.md section 8c last row, section 8e)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -227,3 +228,25 @@ def test_text_segmentation_methods_match_reference_outputs():
         assert seg.split_big_text(t, 40) == want
     with pytest.raises(ValueError):
         seg.get_method("cut9")
+
+
+def test_tts_config_dict_yaml_and_defaults(tmp_path):
+    """reference TTS_Config surface (TTS.py:217-410): dict with sections or custom keys, YAML path (created when missing),
+    save / reload round trip, languages per version, equality by path."""
+    from gsv.TTS_infer_pack.TTS import TTS_Config
+    c = TTS_Config({"device": "cuda:0", "version": "v2", "max_batch": 4})
+    assert c.version == "v2" and c.max_batch == 4 and c.is_half and not c.use_vocoder and "yue" in c.languages
+    assert c.t2s_weights_path.endswith("s1bert25hz-5kh-longer-epoch=12-step=369668.ckpt")
+    c2 = TTS_Config({"custom": {"device": "cuda:0", "is_half": False, "version": "v3", "t2s_weights_path": "a", "vits_weights_path": "b"}})
+    assert c2.version == "v3" and not c2.is_half and c2.use_vocoder and c2.precision == torch.float32
+    assert TTS_Config({"version": "v1"}).languages == ["auto", "en", "zh", "ja", "all_zh", "all_ja"]
+    p = str(tmp_path / "cfg" / "tts_infer.yaml")
+    c3 = TTS_Config(p)                                        # missing file: written from the defaults
+    assert os.path.exists(p) and c3.version == "v2"
+    c2.save_configs(p)
+    c4 = TTS_Config(p)
+    assert (c4.version, c4.is_half, c4.t2s_weights_path) == ("v3", False, "a") and c4 == TTS_Config(p) and hash(c4) == hash(p)
+    assert set(c4.update_configs()) == {"device", "is_half", "version", "t2s_weights_path", "vits_weights_path", "bert_base_path",
+                                        "cnhuhbert_base_path"}
+    with pytest.raises(NotImplementedError):
+        TTS_Config({"version": "v9"})
