@@ -87,3 +87,38 @@ def test_version_tables_equal_the_reference():
     assert {k.decode(): v for k, v in pc.head2version.items()} == t["head2version"]
     assert {k: v.decode() for k, v in pc.model_version2byte.items()} == t["model_version2byte"]
     assert pc.hash_pretrained_dict == t["hash_pretrained_dict"]
+
+
+def test_streaming_framing_and_tts_handle():
+    """api_v2.py:300-373: streaming "wav" = one header-only RIFF chunk, then raw fragments; non-streaming = one packed body;
+    failures become the reference's 400 payload; ogg is refused (libsndfile absent), aac needs ffmpeg."""
+    import numpy as np
+    from gsv import wire
+
+    class Fake:
+        def run(self, req):
+            assert req.get("return_fragment", False) == bool(req.get("streaming_mode", False))
+            if req.get("text") == "boom":
+                raise RuntimeError("engine failed")
+            for i in range(3 if req.get("return_fragment") else 1):
+                yield 32000, np.full(10 + i, i + 1, dtype=np.int16)
+
+    code, mt, it = wire.tts_handle(Fake(), {"text": "x", "streaming_mode": True, "media_type": "wav"})
+    chunks = list(it)
+    assert code == 200 and mt == "audio/wav" and len(chunks) == 4
+    assert chunks[0] == wire.wave_header_chunk(sample_rate=32000) and len(chunks[0]) == 44
+    assert chunks[1] == np.full(10, 1, dtype=np.int16).tobytes() and chunks[3] == np.full(12, 3, dtype=np.int16).tobytes()
+    code, mt, body = wire.tts_handle(Fake(), {"text": "x", "media_type": "wav"})
+    assert code == 200 and body[:4] == b"RIFF" and len(body) == 44 + 20
+    code, mt, body = wire.tts_handle(Fake(), {"text": "x", "media_type": "raw", "streaming_mode": True})
+    assert [len(c) for c in body] == [20, 22, 24]
+    code, mt, body = wire.tts_handle(Fake(), {"text": "boom"})
+    assert code == 400 and body == {"message": "tts failed", "Exception": "engine failed"}
+    code, mt, body = wire.tts_handle(Fake(), {"text": "x", "media_type": "ogg"})
+    assert code == 400 and "libsndfile" in body["Exception"]
+    import shutil
+    if shutil.which("ffmpeg") is None:
+        code, _, body = wire.tts_handle(Fake(), {"text": "x", "media_type": "aac"})
+        assert code == 400 and "ffmpeg" in body["Exception"]
+    app = wire.create_app(Fake())                        # the reference's routes exist
+    assert {r.path for r in app.routes if hasattr(r, "methods")} >= {"/tts"}
