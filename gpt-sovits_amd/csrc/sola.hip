@@ -86,6 +86,49 @@ __global__ void sola_gather_kernel(const float* __restrict__ frags, const long l
   for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (long long)gridDim.x * blockDim.x) dst[k] = src[k];
 }
 
+// ---- H13: peak normalisation + silence gaps + int16 conversion (reference TTS.py:1377-1429) --------------------------
+// One workgroup per fragment, fragments already in output order.  Pass 1: peak = max|x| over the fragment (a NaN anywhere
+// makes the reference's `max > 1` test false, so it disables the division here too).  Pass 2 (served from L2): the
+// reference's arithmetic in the fragment's own dtype T -- x / peak in T when peak > 1, then * 32768 in T (numpy keeps
+// float16 for float16 * int) -- truncated to int32 and wrapped to int16, followed by `gap` zero samples.
+struct PostTable {
+  const void* src[32];
+  long long dst[32];
+  int len[32];
+};
+
+template <typename T>
+__global__ __launch_bounds__(1024) void postprocess_kernel(PostTable tab, int gap, short* __restrict__ out) {
+  __shared__ float red[16];
+  __shared__ int red_nan[16];
+  const T* __restrict__ x = (const T*)tab.src[blockIdx.x];
+  const int n = tab.len[blockIdx.x];
+  short* __restrict__ o = out + tab.dst[blockIdx.x];
+  float peak = 0.f;
+  int nan = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float v = fabsf((float)x[i]);
+    nan |= (v != v);
+    peak = fmaxf(peak, v);
+  }
+  peak = wave_max(peak);
+  nan = __any(nan);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = peak; red_nan[threadIdx.x >> 6] = nan; }
+  __syncthreads();
+  peak = red[0];
+  nan = red_nan[0];
+  for (int w = 1; w < 16; ++w) { peak = fmaxf(peak, red[w]); nan |= red_nan[w]; }
+  const bool divide = !nan && peak > 1.f;
+  const T denom = (T)peak;                                     // exact: the peak is one of the fragment's values
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    T v = x[i];
+    if (divide) v = (T)((float)v / (float)denom);
+    const T m = (T)((float)v * 32768.f);
+    o[i] = (short)(int)(float)m;
+  }
+  for (int i = threadIdx.x; i < gap; i += 1024) o[n + i] = 0;
+}
+
 }  // namespace gsv
 
 extern "C" int gsv_sola(float* frags, const int* lens, int n, int overlap, float* out, int* out_len, gsv_stream_t stream) {
@@ -137,4 +180,30 @@ extern "C" int gsv_sola(float* frags, const int* lens, int n, int overlap, float
   if (rc == GSV_OK && e != hipSuccess) fail(e, "sync");
   (void)hipFree(scratch);
   return rc;
+}
+
+
+extern "C" int gsv_postprocess(const void* const* frags, const int* lens, int n, int dtype, int gap, int16_t* out,
+                               gsv_stream_t stream) {
+  using namespace gsv;
+  GSV_REQUIRE(n >= 0 && gap >= 0 && (dtype == GSV_F16 || dtype == GSV_F32), "postprocess: bad argument");
+  if (n == 0) return GSV_OK;
+  GSV_REQUIRE(frags && lens && out, "postprocess: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  long long off = 0;
+  for (int base = 0; base < n; base += 32) {
+    PostTable tab{};
+    const int m = n - base < 32 ? n - base : 32;
+    for (int i = 0; i < m; ++i) {
+      GSV_REQUIRE(lens[base + i] >= 0 && (lens[base + i] == 0 || frags[base + i]), "postprocess: fragment %d is null", base + i);
+      tab.src[i] = frags[base + i];
+      tab.len[i] = lens[base + i];
+      tab.dst[i] = off;
+      off += (long long)lens[base + i] + gap;
+    }
+    if (dtype == GSV_F16) hipLaunchKernelGGL(postprocess_kernel<_Float16>, dim3(m), dim3(1024), 0, s, tab, gap, (short*)out);
+    else hipLaunchKernelGGL(postprocess_kernel<float>, dim3(m), dim3(1024), 0, s, tab, gap, (short*)out);
+    GSV_HIP(hipGetLastError());
+  }
+  return GSV_OK;
 }

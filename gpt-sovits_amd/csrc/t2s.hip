@@ -1520,6 +1520,10 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
       a.ytok = h->d_ytok; a.ycap = h->ycap; a.sp = h->d_sp; a.e_audio = h->e_audio; a.pe = h->pe; a.alpha_a = h->alpha_a;
       a.ybuf = h->ybuf; a.logits_out = h->logits; a.hop = m.hop; a.err = m.err; a.B = h->B; a.L = h->cfg.n_layer; a.V = h->cfg.vocab;
       a.nsteps = budget - 1; a.map_shared = map_local ? 0 : 1;
+      // bits 0-3: hops (A, B, C, D) that poll one granule per line first; bits 8-12: 16ths of the lines that may still be
+      // missing when the full passes start
+      static const int hint_mask = getenv("GSV_MEGA_HINT") ? atoi(getenv("GSV_MEGA_HINT")) : (15 | (2 << 8));
+      a.hint_mask = hint_mask;
       // measurement runs: GSV_MEGA_PROF=<file> dumps in-kernel shader-clock stamps of one (step, layer) for every wave
       const char* prof_path = getenv("GSV_MEGA_PROF");
       unsigned long long* d_prof = nullptr;

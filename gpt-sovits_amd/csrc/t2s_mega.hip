@@ -79,8 +79,8 @@ constexpr int L_AT = L_XS + RMAX * XS_LD * 2;                 // half [RMAX][XS_
 constexpr int L_HS = L_AT + RMAX * XS_LD * 2;                 // half [RMAX][HS_LD] FFN hidden
 constexpr int L_RED = L_HS + RMAX * HS_LD * 2;                // f4 [24][64] split-K partials
 constexpr int L_QKV = L_RED + 24 * 64 * 16;                   // half [2][3][32] q,k,v of the own rows
-constexpr int L_ATT = L_QKV + 2 * 3 * 32 * 2;                 // float [8] m + [8][36] acc,l (8 attention waves)
-constexpr int L_STAGE = L_ATT + 32 + 8 * 36 * 4;              // 4 x 1 KB: per-wave transposition buffers of the publishers
+constexpr int L_ATT = L_QKV + 2 * 3 * 32 * 2;                 // float [8] m + [8 waves][4 rows of 16 lanes][36] acc,l partials
+constexpr int L_STAGE = L_ATT + 32 + 8 * 4 * 36 * 4;          // 4 x 1 KB: per-wave transposition buffers of the publishers
 constexpr int L_ST = L_STAGE + 4 * 1024;                      // int: active[RMAX], kvlen[RMAX], step[RMAX], abort, any_active
 constexpr int L_SEEN = L_ST + 64;                             // bytes [VPAD]
 constexpr int L_KV = (L_SEEN + VPAD + 63) & ~63;              // [2 rows][K|V][KV_CAP][64 B]
@@ -92,6 +92,31 @@ __device__ __forceinline__ void gstore(gu64* p, unsigned tag, unsigned val) {
   __hip_atomic_store(p, ((u64)tag << 32) | val, RLX_AGENT);           // global_store_dwordx2 ... sc1 (one untorn granule)
 }
 __device__ __forceinline__ u64 gload(gu64* p) { return __hip_atomic_load(p, RLX_AGENT); }   // global_load_dwordx2 ... sc1
+
+// Cross-lane reductions on the VALU's data-parallel primitives (DPP) instead of __shfl_xor: hipcc lowers a shuffle to
+// ds_bpermute_b32, an LDS-crossbar round trip of ~100 cycles, and the reductions here are dependent chains of 6 (wave sum /
+// max) to 36 (attention) of them per layer.  quad_perm swaps inside quads, row_half_mirror / row_mirror fold 8 / 16 lanes
+// (a sum or max does not care that a mirror is not an xor), the four 16-lane rows are folded through v_readlane.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+__device__ __forceinline__ float rl_f(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_f<DPP_QUAD_XOR1>(v);
+  v += dpp_f<DPP_QUAD_XOR2>(v);
+  v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_f<DPP_ROW_MIRROR>(v);
+  return (rl_f(v, 0) + rl_f(v, 16)) + (rl_f(v, 32) + rl_f(v, 48));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v));
+  v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v));
+  v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+  return fmaxf(fmaxf(rl_f(v, 0), rl_f(v, 16)), fmaxf(rl_f(v, 32), rl_f(v, 48)));
+}
 
 __device__ __forceinline__ unsigned pack_h2(float a, float b) {
   const h2 v = (h2){(_Float16)a, (_Float16)b};
@@ -117,6 +142,7 @@ struct Ctx {
   int group, member, head, half, R;
   gu64* hop;
   gu32* err;
+  int hint_miss16;              // hint phase ends when at most this many 16ths of the polled lines are still missing
   unsigned long long* prof;     // this wave's 32 stamp slots or null
   bool prof_on;
 };
@@ -159,12 +185,12 @@ __device__ __noinline__ void mega_fail(const Ctx& c, unsigned epoch, unsigned co
 // one wave re-reads N granules per lane (granule k*64 + lane) of ONE or TWO rows (g1 may be null) until every tag equals `epoch`
 template <int N>
 __device__ __forceinline__ bool sweep2(const Ctx& c, gu64* g0, gu64* g1, int nvalid, unsigned epoch, unsigned (&v0)[N],
-                                       unsigned (&v1)[N], unsigned code) {
+                                       unsigned (&v1)[N], unsigned code, bool hint = true) {
   // Every producer writes whole 128-B lines (16 granules) with one store instruction, so the LAST granule of each line is
   // polled first: one load per lane and row covers 64 lines, a 16th of a full pass.  When most lines are there the rows are
   // read in full -- and still checked tag by tag (the hint is an optimisation: the data remains its own flag).  Full-row
   // polling by 4 waves x 256 CUs was ~8 TB/s of fabric traffic by itself.
-  {
+  if (hint) {
     const int nlines = (nvalid + 15) >> 4;
     for (unsigned spins = 0;; ++spins) {
       int miss = 0;
@@ -177,7 +203,7 @@ __device__ __forceinline__ bool sweep2(const Ctx& c, gu64* g0, gu64* g1, int nva
         }
       }
       // most lines there: the stragglers are at most one poll away, go on with full passes (one round trip fewer at the end)
-      if (__popcll(__ballot(miss != 0)) * 4 <= nlines) break;
+      if (__popcll(__ballot(miss != 0)) * 16 <= nlines * c.hint_miss16) break;
       if (spins > SPIN_MAX || *st_abort(c) || (spins & 1023u) == 1023u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
         mega_fail(c, epoch, code | 0x100u);
         return false;
@@ -212,9 +238,10 @@ __device__ __forceinline__ bool sweep2(const Ctx& c, gu64* g0, gu64* g1, int nva
 }
 
 template <int N>
-__device__ __forceinline__ bool sweep(const Ctx& c, gu64* g, int nvalid, unsigned epoch, unsigned (&v)[N], unsigned code) {
+__device__ __forceinline__ bool sweep(const Ctx& c, gu64* g, int nvalid, unsigned epoch, unsigned (&v)[N], unsigned code,
+                                      bool hint = true) {
   unsigned dummy[N];
-  return sweep2<N>(c, g, nullptr, nvalid, epoch, v, dummy, code);
+  return sweep2<N>(c, g, nullptr, nvalid, epoch, v, dummy, code, hint);
 }
 
 // LayerNorm of one row held as 8 values per lane (element k*64 + lane); gamma == null: identity (layer 0's embedding)
@@ -226,11 +253,11 @@ __device__ __forceinline__ void ln_row(const Ctx& c, int row, const unsigned (&v
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += x[k];
-    const float mean = wave_sum(s) * (1.f / D);
+    const float mean = wave_sum_dpp(s) * (1.f / D);
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const float dl = x[k] - mean; q += dl * dl; }
-    const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + 1e-5f);
+    const float rstd = rsqrtf(wave_sum_dpp(q) * (1.f / D) + 1e-5f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = (x[k] - mean) * rstd * gm[k] + bt[k];
   }
@@ -309,8 +336,8 @@ __device__ __forceinline__ void attention_part(const MegaArgs& a, const Ctx& q, 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       sc = __builtin_amdgcn_fdot2((h2v){qv[2 * i], qv[2 * i + 1]}, (h2v){kk[2 * i], kk[2 * i + 1]}, sc, false);
-    sc += __shfl_xor(sc, 1, 64);
-    sc += __shfl_xor(sc, 2, 64);
+    sc += dpp_f<DPP_QUAD_XOR1>(sc);            // the 4 lanes of a key are one quad
+    sc += dpp_f<DPP_QUAD_XOR2>(sc);
     return sc * scale;
   };
   const unsigned char* kimg = smem + L_KV + (ro * 2 + 0) * KV_CAP * 64;
@@ -366,24 +393,29 @@ __device__ __forceinline__ void attention_part(const MegaArgs& a, const Ctx& q, 
       }
     }
   }
-  const float wm = wave_max(m);
+  const float wm = wave_max_dpp(m);
   const float f = (m == -INFINITY) ? 0.f : __expf(m - wm);
   lsum *= f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] *= f;
+  // sum over the 4 key slots of each 16-lane row (lanes of equal `part`): two row shifts, lanes 12..15 hold the row's totals;
+  // the 4 rows (and the row's other waves) are added by the combine step from LDS
+  lsum += dpp_f<DPP_ROW_SHR4>(lsum);
+  lsum += dpp_f<DPP_ROW_SHR8>(lsum);
 #pragma unroll
-  for (int o = 4; o < 64; o <<= 1) {
-    lsum += __shfl_xor(lsum, o, 64);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+  for (int i = 0; i < 8; ++i) {
+    acc[i] += dpp_f<DPP_ROW_SHR4>(acc[i]);
+    acc[i] += dpp_f<DPP_ROW_SHR8>(acc[i]);
   }
   float* s_m = (float*)(smem + L_ATT);
-  float* s_acc = s_m + 8;
-  if (q.lane < 4) {
+  float* s_acc = s_m + 8;                              // [aw][row][36]
+  if ((q.lane & 15) >= 12) {
+    const int row = q.lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s_acc[aw * 36 + q.lane * 8 + i] = acc[i];
-    if (q.lane == 0) { s_acc[aw * 36 + 32] = lsum; s_m[aw] = wm; }
+    for (int i = 0; i < 8; ++i) s_acc[(aw * 4 + row) * 36 + part * 8 + i] = acc[i];
+    if (part == 0) s_acc[(aw * 4 + row) * 36 + 32] = lsum;
   }
+  if (q.lane == 0) s_m[aw] = wm;
 }
 
 // K/V image staging by the comm waves: the cached K and V of the member's own rows for the NEXT layer go global -> registers
@@ -438,6 +470,11 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
   KvStage kvs;
   kv_stage_load(a, q, 0, 0, kvs);
   kv_stage_store(q, 0, kvs);                         // layer 0's image (the attention waves read it after B1 + two compute barriers)
+  // LayerNorm parameters of the current layer, loaded in P1's poll-free stretch (a load issued right before a sweep would sit
+  // in front of its polls: a wave's memory operations return in order): norm1 for hop C, norm2 for the next hop A / the tail
+  float gC[8], bC[8], gA[8], bA[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gC[k] = bC[k] = gA[k] = bA[k] = 0.f;
   for (int s = 0; s < a.nsteps; ++s) {
     const unsigned ep0 = (unsigned)s * (unsigned)EPS;  // epoch of hop i of this step = ep0 + i + 1
     for (int l = 0; l < a.L; ++l) {
@@ -451,24 +488,16 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         const unsigned ep = ep0 + 4 * l + 1;
         if (ra < R) {
           unsigned va[8];
-          float gm[8], bt[8];
-          const float* gp = l > 0 ? lp - FP_LAYER + FP_N2W : nullptr;
-          const float* bp = l > 0 ? lp - FP_LAYER + FP_N2B : nullptr;
-          if (gp) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { gm[k] = gp[k * 64 + q.lane]; bt[k] = bp[k * 64 + q.lane]; }
-          }
+          const bool has_ln = l > 0;                       // layer 0's input is the embedding itself
           bool ok = true;
           if (s == 0 && l == 0) {
             const float* ya = a.ybuf + (size_t)(q.group + MG_GROUPS * ra) * D;
 #pragma unroll
             for (int k = 0; k < 8; ++k) va[k] = __float_as_uint(ya[k * 64 + q.lane]);
           } else {
-            ok = sweep<8>(q, q.hop + HOP_A + ra * 512, 512, ep, va, 1u);
+            ok = sweep<8>(q, q.hop + HOP_A + ra * 512, 512, ep, va, 1u, a.hint_mask & 1);
           }
-          if (ok) {
-            ln_row(q, ra, va, gp ? gm : nullptr, bt);
-          }
+          if (ok) ln_row(q, ra, va, has_ln ? gA : nullptr, bA);
         }
         if (l == 0 && s > 0 && q.cw == 0) {
           // row state published by the samplers with the embedding: {active} per row
@@ -490,6 +519,11 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
       const int kv_nl = l + 1 < a.L ? l + 1 : 0, kv_extra = l + 1 < a.L ? 0 : 1;
       const bool kv_more = l + 1 < a.L || s + 1 < a.nsteps;
       if (kv_more) kv_stage_load(a, q, kv_nl, kv_extra, kvs);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        gC[k] = lp[FP_N1W + k * 64 + q.lane]; bC[k] = lp[FP_N1B + k * 64 + q.lane];
+        gA[k] = lp[FP_N2W + k * 64 + q.lane]; bA[k] = lp[FP_N2B + k * 64 + q.lane];
+      }
       MG_STAMP(q, 4);
       MG_BAR();                                                          // B4: the attention is done, the K/V image is free
       MG_STAMP(q, 5);
@@ -498,7 +532,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
       // ---- hop B: attention output of all heads -> AT
       if (sweeper && ra < R) {
         unsigned va[4];
-        if (sweep<4>(q, q.hop + HOP_B + ra * 256, 256, ep0 + 4 * l + 2, va, 3u)) {
+        if (sweep<4>(q, q.hop + HOP_B + ra * 256, 256, ep0 + 4 * l + 2, va, 3u, a.hint_mask & 2)) {
           unsigned* at = (unsigned*)(smem + L_AT);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -516,12 +550,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
       // ---- hop C: y1 -> LayerNorm1 -> XS / XRES
       if (sweeper && ra < R) {
         unsigned va[8];
-        float gm[8], bt[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { gm[k] = lp[FP_N1W + k * 64 + q.lane]; bt[k] = lp[FP_N1B + k * 64 + q.lane]; }
-        if (sweep<8>(q, q.hop + HOP_C + ra * 512, 512, ep0 + 4 * l + 3, va, 4u)) {
-          ln_row(q, ra, va, gm, bt);
-        }
+        if (sweep<8>(q, q.hop + HOP_C + ra * 512, 512, ep0 + 4 * l + 3, va, 4u, a.hint_mask & 4)) ln_row(q, ra, va, gC, bC);
       }
       MG_STAMP(q, 9);
       MG_BAR();                                                          // B1
@@ -533,7 +562,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
       // ---- hop D: h -> HS
       if (sweeper && ra < R) {
         unsigned va[16];
-        if (sweep<16>(q, q.hop + HOP_D + ra * 1024, 1024, ep0 + 4 * l + 4, va, 5u)) {
+        if (sweep<16>(q, q.hop + HOP_D + ra * 1024, 1024, ep0 + 4 * l + 4, va, 5u, a.hint_mask & 8)) {
           unsigned* hs = (unsigned*)(smem + L_HS);
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
@@ -550,17 +579,11 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
     }
     relaunder(q);
     // ---- tail: hop A' -> LayerNorm2 of the last layer -> XS; then the samplers
-    const float* lpl = a.fpack + (size_t)(a.L - 1) * FP_LAYER;
     const unsigned epA = ep0 + 4 * a.L + 1, epE = ep0 + 4 * a.L + 2;
     if (sweeper && q.cw < R) {
       const int ra = q.cw;
       unsigned va[8];
-      float gm[8], bt[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { gm[k] = lpl[FP_N2W + k * 64 + q.lane]; bt[k] = lpl[FP_N2B + k * 64 + q.lane]; }
-      if (sweep<8>(q, q.hop + HOP_A + ra * 512, 512, epA, va, 6u)) {
-        ln_row(q, ra, va, gm, bt);
-      }
+      if (sweep<8>(q, q.hop + HOP_A + ra * 512, 512, epA, va, 6u, a.hint_mask & 1)) ln_row(q, ra, va, gA, bA);   // norm2 of the last layer
     }
     MG_BAR();                                                            // B1
     if (*st_abort(q)) return;
@@ -724,8 +747,9 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
           for (int w = 0; w < 2; ++w) {
             const float mw = s_m[2 * ro + w];
             const float ew = mw == -INFINITY ? 0.f : __expf(mw - M);
-            Lsum += s_acc[(2 * ro + w) * 36 + 32] * ew;
-            num += s_acc[(2 * ro + w) * 36 + e] * ew;
+            const float* pa = s_acc + (2 * ro + w) * 4 * 36;
+            Lsum += ((pa[32] + pa[36 + 32]) + (pa[72 + 32] + pa[108 + 32])) * ew;
+            num += ((pa[e] + pa[36 + e]) + (pa[72 + e] + pa[108 + e])) * ew;
           }
           o = num / Lsum;
         }
@@ -881,6 +905,7 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   c.err = (gu32*)a.err;
   c.prof = a.prof ? a.prof + ((size_t)blockIdx.x * 8 + c.wave) * 32 : nullptr;
   c.prof_on = false;
+  c.hint_miss16 = (a.hint_mask >> 8) & 31;
   const int lane = c.lane, R = c.R;
   const StepParams sp = *a.sp;
 

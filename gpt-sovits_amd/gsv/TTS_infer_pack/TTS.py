@@ -505,35 +505,25 @@ class TTS:
         int(sr*interval) zeros, restore order, concatenate, scale by 32768 and truncate to int16."""
         if super_sampling:
             raise NotImplementedError("audio super-sampling (v3 only) is out of scope")
-        dev = self.configs.device
-        zero = torch.zeros(int(self.configs.sampling_rate * fragment_interval), dtype=self.precision, device=dev)
-        frags = [f for batch in audio for f in batch]
-        # per-fragment peak normalisation as ONE segmented reduction + ONE division over the concatenated fragments
-        # (x / max(peak, 1) == x when peak <= 1); the reference loops over fragments with a host sync each (TTS.py:1391-1396)
-        lens = [int(f.shape[0]) for f in frags]
-        flat_in = torch.cat(frags, dim=0) if frags else zero[:0]
-        lens_t = torch.tensor(lens, dtype=torch.int64, device=dev)
-        if flat_in.numel():
-            peaks = torch.segment_reduce(flat_in.abs().float(), "max", lengths=lens_t, unsafe=True).clamp_min(0)
-            peaks = torch.nan_to_num(peaks, nan=0.0, posinf=float("inf"), neginf=0.0)       # empty fragments
-            denom = torch.where(peaks > 1, peaks, torch.ones_like(peaks)).to(flat_in.dtype)
-            flat_in = flat_in / torch.repeat_interleave(denom, lens_t, output_size=flat_in.numel())
-        pieces = list(torch.split(flat_in, lens)) if lens else []
-        k = 0
-        for i, batch in enumerate(audio):
-            for j in range(len(batch)):
-                audio[i][j] = pieces[k]
-                k += 1
+        import ctypes as C
+        from .. import _lib
+        dev = torch.device(self.configs.device)
+        if dev.type != "cuda":
+            raise RuntimeError("audio_postprocess is a HIP kernel (gsv_postprocess); there is no CPU path")
+        gap = int(self.configs.sampling_rate * fragment_interval)
         flat = self.recovery_order(audio, batch_index_list) if split_bucket else [f for b in audio for f in b]
-        self.last_fragment_lengths = [int(f.shape[0]) + int(zero.shape[0]) for f in flat]      # used by gsv.sharding
-        parts = []
-        for f in flat:
-            parts.append(f)
-            parts.append(zero)
-        wav = torch.cat(parts, dim=0) if parts else zero[:0]
-        # (x * 32768).astype(int16): C-style truncation, +32768 wraps to -32768 exactly as numpy does on the
-        # reference's host path; done on the device so only int16 crosses PCIe
-        pcm = (wav * 32768).to(torch.int32).to(torch.int16)
+        flat = [f.to(dev, self.precision).contiguous().view(-1) for f in flat]
+        lens = [int(f.shape[0]) for f in flat]
+        self.last_fragment_lengths = [n + gap for n in lens]                                   # used by gsv.sharding
+        # one launch (`gsv_postprocess`, csrc/sola.hip): peak, division, gaps, order and the int16 conversion -- the
+        # reference loops over fragments on the host with a sync each (TTS.py:1391-1396); only int16 crosses PCIe
+        with torch.cuda.device(dev):
+            pcm = torch.empty(sum(lens) + gap * len(lens), dtype=torch.int16, device=dev)
+            ptrs = (C.c_void_p * max(len(flat), 1))(*[f.data_ptr() for f in flat])
+            arr = (C.c_int * max(len(flat), 1))(*lens)
+            st = torch.cuda.current_stream(dev)
+            _lib.check(_lib.lib().gsv_postprocess(ptrs, arr, len(flat), _lib.GSV_F16 if self.precision == torch.float16 else
+                                                  _lib.GSV_F32, gap, pcm.data_ptr(), C.c_void_p(st.cuda_stream)), "gsv_postprocess")
         return sr, self._to_host(pcm)
 
     def _to_host(self, t: torch.Tensor) -> np.ndarray:

@@ -97,6 +97,7 @@ _SIGS = {
     "gsv_cfm_inference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
     "gsv_sola": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "gsv_postprocess": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gsv_aa_act_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gsv_op_flash_attn64": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -228,6 +228,14 @@ int gsv_cfm_inference(gsv_cfm_t* h, const float* mu, const float* prompt, int B,
 int gsv_sola(float* frags, const int* lens, int n, int overlap, float* out, int* out_len, gsv_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * H13 audio post-processing (replaces TTS.audio_postprocess, TTS_infer_pack/TTS.py:1377-1429): per fragment divide by
+ * its peak when the peak exceeds 1, append `gap` zero samples, concatenate in the order given, scale by 32768 in the
+ * fragments' dtype and truncate to int16 (numpy's astype wrap).  frags [host] n device pointers (output order),
+ * lens [host] n sample counts, out [dev] int16 with capacity sum(lens) + n * gap.  Asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------- */
+int gsv_postprocess(const void* const* frags, const int* lens, int n, int dtype, int gap, int16_t* out, gsv_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * BigVGAN anti-aliased snake activation (v3 vocoder), the reference's one native kernel.
  * x,y [dev] [B][C][T] of `dtype`; up12/dn12 [dev] 12 filter taps; log_alpha/log_beta [dev] [C].
  * T == 0 returns GSV_OK without a launch (anti_alias_activation_cuda.cu:193-196).

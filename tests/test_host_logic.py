@@ -48,18 +48,15 @@ def test_to_batch_prepends_prompt_and_reports_max_len():
     assert float(b["all_bert_features"][0][:, :3].min()) == 1.0 and float(b["all_bert_features"][0][:, 3:].max()) == 0.0
 
 
-def test_recovery_order_and_postprocess_scaling():
+def test_recovery_order():
+    """TTS.py:957-982: fragments return to the input order (the peak / int16 stage is a HIP kernel: tests/test_pipeline_gpu.py)"""
     tts = _tts_cpu()
     index = [[2, 0], [1]]
     audio = [[torch.full((4,), 0.5), torch.tensor([2.0, -4.0, 1.0])], [torch.tensor([0.25, -0.25])]]
-    sr, out = tts.audio_postprocess(audio, 32000, index, 1.0, True, fragment_interval=0.0001)  # 3 zeros
-    assert sr == 32000 and out.dtype == np.int16
-    # order restored: item0 = second fragment of batch 0 (peak 4 > 1 -> divided by 4), item1, item2
-    exp = [0.5, -1.0, 0.25, 0, 0, 0, 0.25, -0.25, 0, 0, 0, 0.5, 0.5, 0.5, 0.5, 0, 0, 0]
-    assert out.tolist() == (np.array(exp) * 32768).astype(np.int16).tolist()
-    assert tts.last_fragment_lengths == [6, 5, 7]
-    # -1.0 * 32768 wraps/clamps exactly like numpy astype on the reference (TTS.py:1421)
-    assert out[1] == np.array([-32768.0]).astype(np.int16)[0]
+    flat = tts.recovery_order(audio, index)
+    assert [f.tolist() for f in flat] == [[2.0, -4.0, 1.0], [0.25, -0.25], [0.5] * 4]
+    with pytest.raises(Exception):                       # no CPU fallback for the post-processing kernel
+        tts.audio_postprocess(audio, 32000, index, 1.0, True, fragment_interval=0.0001)
 
 
 def test_deal_contiguous_batches_and_wire_format_roundtrip():

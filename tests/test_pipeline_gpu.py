@@ -185,3 +185,44 @@ def test_none_bert_features_equal_zero_features():
         (sr, audio), = list(tts.run(dict(params, segments=segs)))
         outs.append(audio.copy())
     assert outs[0].size > 0 and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_audio_postprocess_kernel_matches_reference_arithmetic(half):
+    """H13 (`gsv_postprocess`) against the reference's host arithmetic (TTS.py:1377-1429) in the fragments' own dtype:
+    peak division only above 1, silence gaps, order recovery, x32768 in that dtype, numpy's astype(int16) wrap;
+    bit-exact, including 70 fragments (three table launches), an empty fragment and a fragment holding a NaN."""
+    from gsv.TTS_infer_pack.TTS import TTS
+    tts = TTS({"device": DEV, "is_half": half, "version": "v2"})
+    dt, npdt = (torch.float16, np.float16) if half else (torch.float32, np.float32)
+    g = torch.Generator().manual_seed(5)
+    # hand-computed case first (the old host-logic test): item0 has peak 4 -> divided, -1.0 * 32768 wraps like numpy
+    index = [[2, 0], [1]]
+    audio = [[torch.full((4,), 0.5), torch.tensor([2.0, -4.0, 1.0])], [torch.tensor([0.25, -0.25])]]
+    sr, out = tts.audio_postprocess([[f.to(DEV, dt) for f in b] for b in audio], 32000, index, 1.0, True, fragment_interval=0.0001)
+    exp = [0.5, -1.0, 0.25, 0, 0, 0, 0.25, -0.25, 0, 0, 0, 0.5, 0.5, 0.5, 0.5, 0, 0, 0]
+    assert sr == 32000 and out.dtype == np.int16 and out.tolist() == (np.array(exp) * 32768).astype(np.int16).tolist()
+    assert tts.last_fragment_lengths == [6, 5, 7] and out[1] == -32768
+    # many ragged fragments in shuffled batches
+    lens = [int(v) for v in torch.randint(1, 5000, (70,), generator=g)]
+    lens[7] = 0
+    frags = [((torch.rand(n, generator=g) * 2 - 1) * (0.3 if i % 3 else 1.7)).to(dt) for i, n in enumerate(lens)]
+    frags[11][3] = float("nan")
+    perm = torch.randperm(70, generator=g).tolist()
+    index = [perm[:32], perm[32:50], perm[50:]]
+    batches = [[frags[i].to(DEV) for i in ix] for ix in index]
+    gap = int(32000 * 0.01)
+    sr, out = tts.audio_postprocess(batches, 32000, index, 1.0, True, fragment_interval=0.01)
+    parts = []
+    for f in frags:                                             # reference loop, numpy in the fragment dtype
+        a = f.numpy().astype(npdt)
+        m = np.abs(a).max() if a.size else 0
+        if m > 1:
+            a = a / m
+        parts += [a, np.zeros(gap, npdt)]
+    ref = np.concatenate(parts)
+    with np.errstate(invalid="ignore"):
+        ref16 = (ref * 32768).astype(np.int32).astype(np.int16)
+    nan_at = np.isnan(ref)
+    assert out.shape == ref16.shape and np.array_equal(out[~nan_at], ref16[~nan_at])
+    assert tts.last_fragment_lengths == [n + gap for n in lens]
