@@ -76,7 +76,7 @@ static inline size_t dt_size(int dt) { return dt == GSV_F16 ? 2 : 4; }
 // generic channels-last implicit-GEMM conv (conv_gemm.hip)
 // ------------------------------------------------------------------------------------
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3, ACT_MISH = 4, ACT_CLAMP1 = 5, ACT_SILU = 6, ACT_GELU = 7,
-       ACT_GELU_TANH = 8, ACT_LRELU01 = 9 };
+       ACT_GELU_TANH = 8, ACT_LRELU01 = 9, ACT_LOGCLAMP = 10 /* log(max(u, 1e-5)): mel_processing.py:8-14 */ };
 
 // Transcendental activations live in ONE out-of-line copy per translation unit: the conv epilogues are unrolled
 // 16-64x, and inlining tanhf / expf / log1pf / erff into every instance grew the conv kernels by 26 % and made the
@@ -88,6 +88,7 @@ static __device__ __noinline__ float post_act_slow(int act, float u) {
     case ACT_SILU: return u / (1.f + expf(-u));
     case ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
     case ACT_GELU_TANH: return 0.5f * u * (1.f + tanhf(0.79788456080286536f * (u + 0.044715f * u * u * u)));
+    case ACT_LOGCLAMP: return logf(fmaxf(u, 1e-5f));
     default: return u;
   }
 }

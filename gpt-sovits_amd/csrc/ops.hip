@@ -147,6 +147,18 @@ __global__ void magnitude_kernel(const float* __restrict__ ri, int T, int bins, 
   }
 }
 
+// same magnitude kept frame-major [T][ld] (zero up to ld): the left operand of the mel-filterbank GEMM
+__global__ void magnitude_tm_kernel(const float* __restrict__ ri, int T, int bins, int ld, float eps, float* __restrict__ spec) {
+  const int b = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+  if (b >= ld) return;
+  float v = 0.f;
+  if (b < bins) {
+    const float re = ri[(long long)t * 2 * bins + b], im = ri[(long long)t * 2 * bins + bins + b];
+    v = sqrtf(re * re + im * im + eps);
+  }
+  spec[(long long)t * ld + b] = v;
+}
+
 // y[t][c] = act((x[t][c] - mean_c) * rstd_c * gamma[c] + beta[c]), statistics over t (biased variance), channels-last.
 // Two kernels: per-(channel block, time slice) partial sums -> finalize + apply.
 template <typename T>
@@ -253,9 +265,13 @@ int gsv_op_frame(const float* x, int n, int frame_len, int hop, int pad, int ld,
   return GSV_OK;
 }
 
-int gsv_op_magnitude(const float* re_im, int T, int bins, float eps, float* spec, gsv_stream_t stream) {
+int gsv_op_magnitude(const float* re_im, int T, int bins, float eps, int frame_ld, float* spec, gsv_stream_t stream) {
   GSV_REQUIRE(re_im && spec && T > 0 && bins > 0, "op_magnitude: bad argument");
-  hipLaunchKernelGGL(gsv::magnitude_kernel, dim3(gsv::cdiv(T, 32), gsv::cdiv(bins, 32)), dim3(256), 0, (hipStream_t)stream, re_im, T, bins, eps, spec);
+  GSV_REQUIRE(frame_ld == 0 || frame_ld >= bins, "op_magnitude: frame_ld %d is smaller than %d bins", frame_ld, bins);
+  if (frame_ld == 0)
+    hipLaunchKernelGGL(gsv::magnitude_kernel, dim3(gsv::cdiv(T, 32), gsv::cdiv(bins, 32)), dim3(256), 0, (hipStream_t)stream, re_im, T, bins, eps, spec);
+  else
+    hipLaunchKernelGGL(gsv::magnitude_tm_kernel, dim3(gsv::cdiv(frame_ld, 256), T), dim3(256), 0, (hipStream_t)stream, re_im, T, bins, frame_ld, eps, spec);
   GSV_HIP(hipGetLastError());
   return GSV_OK;
 }

@@ -42,6 +42,20 @@ def denorm_spec(x):
     return (x + 1) / 2 * (spec_max - spec_min) + spec_min
 
 
+def mel_fn(x):
+    """reference TTS.py:67-79 (v3: 24 kHz, n_fft 1024, hop 256, 100 mels)"""
+    from ..module.mel_processing import mel_spectrogram_torch
+    return mel_spectrogram_torch(x, n_fft=1024, win_size=1024, hop_size=256, num_mels=100, sampling_rate=24000, fmin=0, fmax=None,
+                                 center=False)
+
+
+def mel_fn_v4(x):
+    """reference TTS.py:81-93 (v4: 32 kHz, n_fft 1280, hop 320, 100 mels)"""
+    from ..module.mel_processing import mel_spectrogram_torch
+    return mel_spectrogram_torch(x, n_fft=1280, win_size=1280, hop_size=320, num_mels=100, sampling_rate=32000, fmin=0, fmax=None,
+                                 center=False)
+
+
 class NO_PROMPT_ERROR(Exception):
     pass
 
@@ -375,11 +389,12 @@ class TTS:
             raise NotImplementedError("v2Pro / v2ProPlus need the ERes2NetV2 speaker embedding (sv.py:11-32), which is not built: "
                                       "use set_prompt_cache(..., sv_emb=...)")
         raw, raw_sr = load_wav(ref_audio_path)
+        self.prompt_cache["raw_audio"] = raw                     # [channels, n] float32 at raw_sr (TTS.py:759-762), host side
         self.prompt_cache["raw_sr"] = raw_sr
+        self.prompt_cache["ref_mel"] = None                      # v3 / v4: recomputed from raw_audio on first use
         if raw.shape[0] == 2:
             raw = raw.mean(0, keepdims=True)
         audio = torch.from_numpy(resample(raw[:1], raw_sr, self.configs.sampling_rate)).to(self.configs.device)
-        self.prompt_cache["raw_audio"] = audio
         maxx = float(audio.abs().max())
         if maxx > 1:
             audio = audio / min(2.0, maxx)
@@ -534,8 +549,10 @@ class TTS:
     # ---- v3 / v4 synthesis (reference TTS.py:1431-1637) -----------------------------------------
     def _prompt_features(self):
         pc = self.prompt_cache
+        if pc.get("ref_mel") is None and pc.get("raw_audio") is not None:
+            pc["ref_mel"] = self._ref_mel_from_audio(pc["raw_audio"], pc["raw_sr"])
         if pc.get("ref_mel") is None or pc["phones"] is None:
-            raise NO_PROMPT_ERROR("v3/v4 need set_prompt_cache(..., phones=..., ref_mel=...)")
+            raise NO_PROMPT_ERROR("v3/v4 need set_ref_audio(path) or set_prompt_cache(..., phones=..., ref_mel=...)")
         dev = self.configs.device
         spec = pc["refer_spec"][0]
         spec = spec[0] if isinstance(spec, tuple) else spec
@@ -548,6 +565,19 @@ class TTS:
         if T_min > T_ref:
             mel2, fea_ref, T_min = mel2[:, :, -T_ref:], fea_ref[:, :, -T_ref:], T_ref
         return spec, fea_ref, ge, mel2.to(self.precision), T_min
+
+    def _ref_mel_from_audio(self, raw_audio: np.ndarray, raw_sr: int) -> torch.Tensor:
+        """TTS.py:1442-1453 / 1512-1523: mono mix of a stereo file, resampled to the vocoder's rate (24 kHz v3, 32 kHz v4),
+        `mel_fn` / `mel_fn_v4` -> [1, 100, frames] (un-normalised: `_prompt_features` applies norm_spec)."""
+        from ..audio_io import resample
+        audio = np.asarray(raw_audio, dtype=np.float32)
+        if audio.ndim == 1:
+            audio = audio[None]
+        if audio.shape[0] == 2:
+            audio = audio.mean(0, keepdims=True)
+        tgt_sr = 24000 if self.configs.version == "v3" else 32000
+        audio = torch.from_numpy(resample(audio[:1], raw_sr, tgt_sr)).to(self.configs.device)
+        return (mel_fn if self.configs.version == "v3" else mel_fn_v4)(audio)
 
     @torch.no_grad()
     def using_vocoder_synthesis(self, semantic_tokens: torch.Tensor, phones: torch.Tensor, speed: float = 1.0,

@@ -105,7 +105,7 @@ _SIGS = {
                                      C.c_void_p]),
     "gsv_op_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "gsv_op_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
-    "gsv_op_magnitude": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "gsv_op_magnitude": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "gsv_op_channel_norm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_void_p]),
     "gsv_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

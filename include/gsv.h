@@ -278,11 +278,12 @@ int gsv_op_layernorm(const void* x, const void* res, const float* gamma, const f
  * gsv/feature_extractor/cnhubert.py, the GEMMs are gsv_op_conv1d):
  *  gsv_op_frame: out[t][k] = x[reflect(t*hop + k - pad)], k < frame_len, zero up to ld; x [dev] fp32 [n]; out [T_out][ld] of dtype
  *    (torch.stft's reflect framing, reference module/mel_processing.py:55-71; pad = 0: the operand of a strided Conv1d(1, C, k))
- *  gsv_op_magnitude: re_im [dev] fp32 [T][2*bins] (re | im) -> spec [dev] fp32 [bins][T] = sqrt(re^2 + im^2 + eps)  (:73)
+ *  gsv_op_magnitude: re_im [dev] fp32 [T][2*bins] (re | im) -> sqrt(re^2 + im^2 + eps) (:73) as spec [dev] fp32 [bins][T]
+ *    (frame_ld = 0), or frame-major [T][frame_ld] zero-filled beyond bins (the operand of the mel-filterbank GEMM, :138-140)
  *  gsv_op_channel_norm: channels-last [T][C]: per-channel mean / biased variance over T, affine, activation (ACT codes of
  *    gsv_conv_desc.post_act) -- torch.nn.GroupNorm(C, C) of the HuBERT feature extractor; scratch [dev] 128*C floats */
 int gsv_op_frame(const float* x, int n, int frame_len, int hop, int pad, int ld, int T_out, void* out, int dtype, gsv_stream_t stream);
-int gsv_op_magnitude(const float* re_im, int T, int bins, float eps, float* spec, gsv_stream_t stream);
+int gsv_op_magnitude(const float* re_im, int T, int bins, float eps, int frame_ld, float* spec, gsv_stream_t stream);
 int gsv_op_channel_norm(const void* x, int T, int C, const float* gamma, const float* beta, float eps, int act, float* scratch,
                         void* y, int dtype, gsv_stream_t stream);
 /* sampling kernel alone: logits [dev] fp32 [B][vocab], prev [dev] int32 [B][prev_len], noise [dev]

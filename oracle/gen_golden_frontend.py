@@ -10,6 +10,11 @@
                               The container has transformers 5.x, the reference pins >= 4.43, <= 4.50 (requirements.txt:21):
                               same architecture and state-dict schema; recorded here because the oracle is that package.
 
+  tests/golden/mel_v3.npz / mel_v4.npz  the reference's `mel_spectrogram_torch` (module/mel_processing.py:93-143) with the v3 /
+                              v4 `mel_fn` parameters (TTS_infer_pack/TTS.py:67-92) on seeded waveforms; librosa is not
+                              installed, so the module's `librosa_mel_fn` is oracle/mel_filterbank.mel here (the filterbank
+                              matrix itself is "parity unpinned", the STFT / magnitude / matmul / log-clamp around it is pinned)
+
     python oracle/gen_golden_frontend.py
 """
 import os
@@ -69,6 +74,17 @@ def main():
         spec = spectrogram_torch(y, 2048, 32000, 640, 2048, center=False)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), spec=spec.numpy().astype(np.float32))
         print(name, tuple(spec.shape), float(spec.max()))
+    import module.mel_processing as mp
+    from oracle import mel_filterbank
+    mp.librosa_mel_fn = mel_filterbank.mel
+    for name, kw, n, seed in (("mel_v3", dict(n_fft=1024, win_size=1024, hop_size=256, num_mels=100, sampling_rate=24000, fmin=0,
+                                             fmax=None, center=False), 36000, 3),
+                              ("mel_v4", dict(n_fft=1280, win_size=1280, hop_size=320, num_mels=100, sampling_rate=32000, fmin=0,
+                                             fmax=None, center=False), 41003, 4)):
+        y = S.make_waveform(n, seed, sr=kw["sampling_rate"]).unsqueeze(0)
+        m = mp.mel_spectrogram_torch(y, **kw)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), mel=m.numpy().astype(np.float32))
+        print(name, tuple(m.shape), float(m.min()), float(m.max()))
 
 
 if __name__ == "__main__":

@@ -34,6 +34,22 @@ def test_spectrogram_matches_reference(name, n, seed):
         spectrogram_torch(y, 2048, 32000, 640, 2048, center=True)
 
 
+@pytest.mark.parametrize("name,n_fft,hop,sr,n,seed", [("mel_v3", 1024, 256, 24000, 36000, 3), ("mel_v4", 1280, 320, 32000, 41003, 4)])
+def test_mel_spectrogram_matches_reference(name, n_fft, hop, sr, n, seed):
+    """v3 / v4 `mel_fn` (TTS.py:67-93): DFT GEMM + frame-major magnitude + filterbank GEMM with the log-clamp epilogue vs the
+    reference's mel_spectrogram_torch (fp32 torch.stft); log-mel values in [-6.7, 0.5]: max-abs <= 2e-3, rms <= 1e-4."""
+    from gsv import synthetic as S
+    from gsv.TTS_infer_pack import TTS as T
+    y = S.make_waveform(n, seed, sr=sr).unsqueeze(0).to(DEV)
+    mel = (T.mel_fn if name == "mel_v3" else T.mel_fn_v4)(y)
+    g = load_golden(name)["mel"]
+    o = mel.cpu().numpy()
+    assert o.shape == g.shape and mel.dtype == torch.float32
+    err, rms = np.abs(o - g).max(), np.sqrt(((o - g) ** 2).mean())
+    print(f"[frontend] {name}: max-abs {err:.2e}, rms {rms:.2e}")
+    assert err <= 2e-3 and rms <= 1e-4
+
+
 def test_hubert_matches_transformers_model():
     """fp16 engine vs transformers.HubertModel fp32 on the same synthetic weights and waveform: last_hidden_state of rms 1.0,
     64 frames x 768; bar: relative rms <= 0.5 %, max-abs <= 3e-2 (measured 0.14 %, 6.8e-3) (fp16 activations through 7 convs + 12 post-LN layers)."""

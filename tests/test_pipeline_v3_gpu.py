@@ -141,3 +141,32 @@ def test_tts_run_v3_end_to_end():
         assert sr == 24000 and audio.dtype == np.int16 and audio.size > 0
         if not par:
             assert np.abs(audio).max() > 0
+
+
+@pytest.mark.parametrize("version", ["v3", "v4"])
+def test_ref_mel_from_raw_audio_feeds_the_prompt(version):
+    """TTS.py:1442-1453: without an explicit ref_mel the prompt mel comes from the cached reference audio -- stereo mixed to
+    mono, resampled to 24 kHz (v3) / 32 kHz (v4), mel_fn / mel_fn_v4, norm_spec, cut to T_min and the last T_ref frames --
+    against the oracle mel of the same resampled samples (the resampler itself is parity-unpinned, see gsv/audio_io.py)."""
+    from gsv.audio_io import resample
+    from gsv.TTS_infer_pack.TTS import norm_spec
+    from oracle import mel_filterbank as omf
+    tts, *_ = _build(version)
+    refer, prompt_sem, prompt_ph, _ = _prompt(tts)
+    tts.prompt_cache["ref_mel"] = None
+    with pytest.raises(Exception):
+        tts._prompt_features()                                   # neither ref_mel nor reference audio
+    sr0 = 32000 if version == "v3" else 24000                    # both versions resample
+    stereo = torch.stack([S.make_waveform(sr0 // 2, 1, sr=sr0), S.make_waveform(sr0 // 2, 2, sr=sr0)]).numpy()
+    tts.prompt_cache["raw_audio"], tts.prompt_cache["raw_sr"] = stereo, sr0
+    spec, fea_ref, ge, mel2, T_min = tts._prompt_features()
+    tgt = 24000 if version == "v3" else 32000
+    mono = torch.from_numpy(resample(stereo.mean(0, keepdims=True), sr0, tgt))
+    n_fft, hop = (1024, 256) if version == "v3" else (1280, 320)
+    ref = norm_spec(omf.mel_spectrogram(mono, n_fft, 100, tgt, hop, n_fft, 0, None))
+    T_ref = VC["T_ref"]
+    full = int(2 * 8 * 1.875) if version == "v3" else 2 * 8 * 2  # fea_ref frames of the 8 prompt tokens before any cut
+    assert ref.shape[2] > full > T_ref and T_min == T_ref and mel2.shape == (1, 100, T_min) and fea_ref.shape[2] == T_min
+    want = ref[:, :, :full]
+    want = want[:, :, -T_ref:] if want.shape[2] > T_ref else want
+    assert (mel2.float().cpu() - want).abs().max() <= 5e-4

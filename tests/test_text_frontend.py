@@ -128,3 +128,39 @@ def test_preprocess_end_to_end_with_builtin_backends(tmp_path):
     assert bert[0].tolist()[:5] == [0.0, 0.0, 1.0, 1.0, 2.0]
     with pytest.raises(NotImplementedError):
         TextPreprocessor().get_phones_and_bert("你好,世界。", "all_zh", "v2")
+
+
+def test_mel_filterbank_known_answers_and_oracle_agreement():
+    """`librosa.filters.mel` restated twice (product: vectorised, oracle: scalar loops; the package is not installed -- the
+    matrix is "parity unpinned" against it).  Known answers from librosa's documentation: hz_to_mel(60) = 0.9,
+    mel_to_hz([1, 2, 3]) = [66.667, 133.333, 200.], mel_frequencies(n_mels=40) (fmax 11025) starts 0, 85.317, 170.635, ... and
+    passes 1024.856, 1119.114, 1222.042 after the 1 kHz knee; filters.mel(sr=22050, n_fft=2048)[0, 1] prints as 0.016."""
+    import numpy as np
+    from gsv.module import mel_processing as mp
+    from oracle import mel_filterbank as omf
+    assert abs(float(mp._hz_to_mel(60)) - 0.9) < 1e-12 and abs(omf.hz_to_mel(60) - 0.9) < 1e-12
+    assert np.allclose(mp._mel_to_hz([1, 2, 3]), [200 / 3, 400 / 3, 200.0])
+    mf = omf.mel_frequencies(40, 0.0, 11025.0)
+    assert [round(v, 3) for v in mf[:3]] == [0.0, 85.317, 170.635] and [round(v, 3) for v in mf[12:15]] == [1024.856, 1119.114, 1222.042]
+    assert mf[-1] == pytest.approx(11025.0)
+    m = mp.librosa_mel_fn(22050, 2048)
+    assert m.shape == (128, 1025) and m.dtype == np.float32 and round(float(m[0, 1]), 3) == 0.016 and float(m[0, 0]) == 0.0
+    for sr, n_fft, n_mels in ((22050, 2048, 128), (24000, 1024, 100), (32000, 1280, 100)):
+        a, b = mp.librosa_mel_fn(sr, n_fft, n_mels, 0, None), omf.mel(sr, n_fft, n_mels, 0, None)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-9 and (a >= 0).all()
+        assert (a.sum(1) > 0).all()                                   # no empty band at these sizes
+
+
+def test_mel_oracle_reproduces_reference_goldens():
+    """oracle/mel_filterbank.mel_spectrogram against tests/golden/mel_v3.npz / mel_v4.npz (the reference's own
+    mel_spectrogram_torch run in the build container with the oracle filterbank in place of librosa's)"""
+    import os
+    import numpy as np
+    from gsv import synthetic as S
+    from oracle import mel_filterbank as omf
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    for name, (n_fft, hop, sr, n, seed) in {"mel_v3": (1024, 256, 24000, 36000, 3), "mel_v4": (1280, 320, 32000, 41003, 4)}.items():
+        g = np.load(os.path.join(gold, name + ".npz"))["mel"]
+        y = S.make_waveform(n, seed, sr=sr).unsqueeze(0)
+        o = omf.mel_spectrogram(y, n_fft, 100, sr, hop, n_fft, 0, None).numpy()
+        assert o.shape == g.shape and np.abs(o - g).max() <= 1e-5
