@@ -76,7 +76,8 @@ static inline size_t dt_size(int dt) { return dt == GSV_F16 ? 2 : 4; }
 // generic channels-last implicit-GEMM conv (conv_gemm.hip)
 // ------------------------------------------------------------------------------------
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3, ACT_MISH = 4, ACT_CLAMP1 = 5, ACT_SILU = 6, ACT_GELU = 7,
-       ACT_GELU_TANH = 8, ACT_LRELU01 = 9, ACT_LOGCLAMP = 10 /* log(max(u, 1e-5)): mel_processing.py:8-14 */ };
+       ACT_GELU_TANH = 8, ACT_LRELU01 = 9, ACT_LOGCLAMP = 10 /* log(max(u, 1e-5)): mel_processing.py:8-14 */,
+       ACT_RELU20 = 11 /* Hardtanh(0, 20): eres2net/ERes2NetV2.py:19-21 */, ACT_LOG_EPS = 12 /* log(max(u, FLT_EPSILON)): eres2net/kaldi.py:654 */ };
 
 // Transcendental activations live in ONE out-of-line copy per translation unit: the conv epilogues are unrolled
 // 16-64x, and inlining tanhf / expf / log1pf / erff into every instance grew the conv kernels by 26 % and made the
@@ -89,6 +90,7 @@ static __device__ __noinline__ float post_act_slow(int act, float u) {
     case ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
     case ACT_GELU_TANH: return 0.5f * u * (1.f + tanhf(0.79788456080286536f * (u + 0.044715f * u * u * u)));
     case ACT_LOGCLAMP: return logf(fmaxf(u, 1e-5f));
+    case ACT_LOG_EPS: return logf(fmaxf(u, 1.1920928955078125e-07f));
     default: return u;
   }
 }
@@ -98,6 +100,7 @@ __device__ __forceinline__ float post_act_f(int act, float u) {
   if (act == ACT_RELU) return fmaxf(u, 0.f);
   if (act == ACT_CLAMP1) return fminf(fmaxf(u, -1.f), 1.f);
   if (act == ACT_LRELU01) return u > 0.f ? u : 0.01f * u;   // nn.LeakyReLU() default slope
+  if (act == ACT_RELU20) return fminf(fmaxf(u, 0.f), 20.f);
   return post_act_slow(act, u);
 }
 

@@ -136,7 +136,7 @@ __global__ void magnitude_kernel(const float* __restrict__ ri, int T, int bins, 
     float v = 0.f;
     if (t < T && b < bins) {
       const float re = ri[(long long)t * 2 * bins + b], im = ri[(long long)t * 2 * bins + bins + b];
-      v = sqrtf(re * re + im * im + eps);
+      v = eps < 0.f ? re * re + im * im : sqrtf(re * re + im * im + eps);
     }
     tile[i][tx] = v;
   }
@@ -154,9 +154,32 @@ __global__ void magnitude_tm_kernel(const float* __restrict__ ri, int T, int bin
   float v = 0.f;
   if (b < bins) {
     const float re = ri[(long long)t * 2 * bins + b], im = ri[(long long)t * 2 * bins + bins + b];
-    v = sqrtf(re * re + im * im + eps);
+    v = eps < 0.f ? re * re + im * im : sqrtf(re * re + im * im + eps);
   }
   spec[(long long)t * ld + b] = v;
+}
+
+// attentional feature fusion mix (eres2net/fusion.py:22-27 with t = tanh(local_att)): out = x (1 + t) + y (1 - t)
+__global__ void aff_mix_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ t, long long n,
+                               float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const float a = t[i]; out[i] = x[i] * (1.f + a) + y[i] * (1.f - a); }
+}
+
+// out[c] = mean over t of x[t][c]  (ERes2NetV2.forward3's temporal mean, ERes2NetV2.py:258); one thread per column, 64-column
+// workgroups x 16 time slices reduced through LDS
+__global__ __launch_bounds__(1024) void time_mean_kernel(const float* __restrict__ x, int T, int ld, float* __restrict__ out) {
+  __shared__ float part[16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < ld) for (int t = sl; t < T; t += 16) s += x[(long long)t * ld + c];
+  part[sl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sl == 0 && c < ld) {
+    float v = 0.f;
+    for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x & 63];
+    out[c] = v / (float)T;
+  }
 }
 
 // y[t][c] = act((x[t][c] - mean_c) * rstd_c * gamma[c] + beta[c]), statistics over t (biased variance), channels-last.
@@ -249,7 +272,8 @@ int gsv_op_conv1d(const gsv_conv_desc* d, int dtype, gsv_stream_t stream) {
   if (d->ldx > 0) a.ldx = d->ldx;
   if (d->ldw > 0) a.ldw = d->ldw;
   if (d->ldy > 0) { a.ldy = d->ldy; a.ldr = d->ldy; }
-  if (d->Z > 1) { a.Z = d->Z; a.xz = d->xz; a.wz = d->wz; a.yz = d->yz; a.bz = d->bz; }
+  if (d->ldr > 0) a.ldr = d->ldr;
+  if (d->Z > 1) { a.Z = d->Z; a.xz = d->xz; a.wz = d->wz; a.yz = d->yz; a.bz = d->bz; a.rz = d->rz ? d->rz : d->yz; }
   return gsv::launch_conv_gemm(dtype, a, (hipStream_t)stream);
 }
 
@@ -272,6 +296,20 @@ int gsv_op_magnitude(const float* re_im, int T, int bins, float eps, int frame_l
     hipLaunchKernelGGL(gsv::magnitude_kernel, dim3(gsv::cdiv(T, 32), gsv::cdiv(bins, 32)), dim3(256), 0, (hipStream_t)stream, re_im, T, bins, eps, spec);
   else
     hipLaunchKernelGGL(gsv::magnitude_tm_kernel, dim3(gsv::cdiv(frame_ld, 256), T), dim3(256), 0, (hipStream_t)stream, re_im, T, bins, frame_ld, eps, spec);
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+int gsv_op_aff_mix(const float* x, const float* y, const float* t, long long n, float* out, gsv_stream_t stream) {
+  GSV_REQUIRE(x && y && t && out && n > 0, "op_aff_mix: bad argument");
+  hipLaunchKernelGGL(gsv::aff_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, t, n, out);
+  GSV_HIP(hipGetLastError());
+  return GSV_OK;
+}
+
+int gsv_op_time_mean(const float* x, int T, int ld, float* out, gsv_stream_t stream) {
+  GSV_REQUIRE(x && out && T > 0 && ld > 0, "op_time_mean: bad argument");
+  hipLaunchKernelGGL(gsv::time_mean_kernel, dim3(gsv::cdiv(ld, 64)), dim3(1024), 0, (hipStream_t)stream, x, T, ld, out);
   GSV_HIP(hipGetLastError());
   return GSV_OK;
 }

@@ -205,6 +205,7 @@ class TTS:
         self._vits_state = None
         self.vocoder = None
         self.cnhuhbert_model = None
+        self.sv_model = None
         self.bert_model = None
         from .TextPreprocessor import TextPreprocessor
         self.text_preprocessor = TextPreprocessor(bert_fn=None, device="cpu")      # reference TTS.py:431-433
@@ -250,6 +251,10 @@ class TTS:
                 dtype=self.precision, n_symbols=hps.get("n_symbols"), **extra, **mcfg)
         v.load_state_dict(state["weight"])
         self.vits_model = v
+        if getattr(v, "is_v2pro", False) and self.sv_model is None:
+            from .. import sv
+            if os.path.exists(sv.sv_path):            # reference TTS.py:487-488 loads it here; without the file: init_sv_model(state_dict=)
+                self.init_sv_model()
 
     def init_vocoder(self, version: Optional[str] = None, state: Optional[dict] = None, weights_path: Optional[str] = None):
         """reference TTS.py:605-660: v3 -> BigVGAN-v2 24 kHz x256, v4 -> the HiFi-GAN `Generator` 48 kHz x480.
@@ -377,17 +382,32 @@ class TTS:
             self.prompt_cache["refer_spec"] = [spec_audio]
         else:
             self.prompt_cache["refer_spec"][0] = spec_audio
+        if spec_audio[1] is not None:
+            # the reference recomputes the embedding inside every run() (TTS.py:1233-1238); it only depends on the reference audio
+            emb = self.sv_model.compute_embedding3(spec_audio[1])
+            cur = self.prompt_cache.get("sv_emb")
+            if cur:
+                cur[0] = emb
+            else:
+                self.prompt_cache["sv_emb"] = [emb]
         if self.vits_model is not None:
             self.vits_model.invalidate_refer()
+
+    def init_sv_model(self, state_dict=None, path: Optional[str] = None):
+        """reference TTS.py:672-675 / sv.py:11-23: the ERes2NetV2 speaker-verification model of v2Pro / v2ProPlus"""
+        from .. import sv
+        if getattr(self, "sv_model", None) is not None and state_dict is None and path is None:
+            return
+        self.sv_model = sv.SV(self.configs.device, self.configs.is_half, state_dict=state_dict, path=path or sv.sv_path)
 
     def _get_ref_spec(self, ref_audio_path: str):
         """reference TTS.py:761-800: mono, resampled to the model rate, divided by min(2, peak) when the peak exceeds 1,
         spectrogram_torch(filter_length, hop_length, win_length, center=False)."""
         from ..audio_io import load_wav, resample
         from ..module.mel_processing import spectrogram_torch
-        if getattr(self.vits_model, "is_v2pro", False):
-            raise NotImplementedError("v2Pro / v2ProPlus need the ERes2NetV2 speaker embedding (sv.py:11-32), which is not built: "
-                                      "use set_prompt_cache(..., sv_emb=...)")
+        is_v2pro = getattr(self.vits_model, "is_v2pro", False) or self.configs.version in ("v2Pro", "v2ProPlus")
+        if is_v2pro and getattr(self, "sv_model", None) is None:
+            raise RuntimeError("v2Pro / v2ProPlus: init_sv_model() first (ERes2NetV2 speaker embedding, sv.py:11-32)")
         raw, raw_sr = load_wav(ref_audio_path)
         self.prompt_cache["raw_audio"] = raw                     # [channels, n] float32 at raw_sr (TTS.py:759-762), host side
         self.prompt_cache["raw_sr"] = raw_sr
@@ -402,7 +422,12 @@ class TTS:
                                  self.configs.win_length, center=False)
         if self.configs.is_half:
             spec = spec.half()
-        return spec, None
+        audio16k = None
+        if is_v2pro:                                             # TTS.py:790-793: the normalised audio again at 16 kHz for the SV model
+            audio16k = torch.from_numpy(resample(audio.cpu().numpy(), self.configs.sampling_rate, 16000)).to(self.configs.device)
+            if self.configs.is_half:
+                audio16k = audio16k.half()
+        return spec, audio16k
 
     def _set_prompt_semantic(self, ref_wav_path: str):
         """reference TTS.py:802-819: 16 kHz audio (3..10 s or OSError) + 0.3 s of silence -> HuBERT last_hidden_state ->
@@ -706,6 +731,28 @@ class TTS:
                 if not os.path.exists(ref_audio_path):
                     raise ValueError(f"{ref_audio_path} not exists")
                 self.set_ref_audio(ref_audio_path)
+            # auxiliary references for multi-speaker tone fusion (reference TTS.py:1098-1113): their spectrograms (and, v2Pro,
+            # speaker embeddings) follow the main one; the style vector is the mean over all of them (models.py:971-985)
+            aux = inputs.get("aux_ref_audio_paths") or []
+            cached = self.prompt_cache.get("aux_ref_audio_paths") or []
+            if "aux_ref_audio_paths" in inputs and not (len(set(aux) & set(cached)) == len(aux) == len(cached)):
+                if self.prompt_cache["refer_spec"] in [None, []]:
+                    raise ValueError("aux_ref_audio_paths need a main reference audio first (ref_audio_path / set_ref_audio)")
+                self.prompt_cache["aux_ref_audio_paths"] = list(aux)
+                self.prompt_cache["refer_spec"] = [self.prompt_cache["refer_spec"][0]]
+                if self.prompt_cache.get("sv_emb"):
+                    self.prompt_cache["sv_emb"] = [self.prompt_cache["sv_emb"][0]]
+                for path in aux:
+                    if path in [None, ""]:
+                        continue
+                    if not os.path.exists(path):
+                        print("音频文件不存在，跳过：", path)
+                        continue
+                    spec_audio = self._get_ref_spec(path)
+                    self.prompt_cache["refer_spec"].append(spec_audio)
+                    if spec_audio[1] is not None:
+                        self.prompt_cache["sv_emb"].append(self.sv_model.compute_embedding3(spec_audio[1]))
+                self.vits_model.invalidate_refer()
             if prompt_text not in [None, ""]:
                 from .text_segmentation_method import splits
                 if prompt_lang not in self.configs.languages:

@@ -48,7 +48,8 @@ class ConvDesc(C.Structure):
                 ("pre_slope", C.c_float), ("post_act", C.c_int), ("scale", C.c_float), ("accumulate", C.c_int),
                 ("out_f32", C.c_int), ("ups_u", C.c_int), ("ups_pad", C.c_int),
                 ("Z", C.c_int), ("xz", C.c_longlong), ("wz", C.c_longlong), ("yz", C.c_longlong),
-                ("ldx", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int), ("gate", C.c_void_p), ("bz", C.c_int)]
+                ("ldx", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int), ("gate", C.c_void_p), ("bz", C.c_int),
+                ("rz", C.c_longlong), ("ldr", C.c_int)]
 
 
 _SIGS = {
@@ -106,6 +107,8 @@ _SIGS = {
     "gsv_op_conv1d": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "gsv_op_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "gsv_op_magnitude": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "gsv_op_aff_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "gsv_op_time_mean": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gsv_op_channel_norm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_void_p]),
     "gsv_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -564,6 +564,60 @@ def make_hubert_state_dict(seed: int = 0, layers: int = 12, hidden: int = 768, f
     return sd
 
 
+def make_eres2net_state_dict(seed: int = 0, m_channels: int = 64, base_width: int = 24, scale: int = 4, expansion: int = 4,
+                             num_blocks=(3, 4, 6, 3)) -> "OrderedDict[str, torch.Tensor]":
+    """fp32 state dict with the key names of the reference's ERes2NetV2(baseWidth=24, scale=4, expansion=4) (sv.py:14,
+    eres2net/ERes2NetV2.py:155-226); BatchNorm running statistics are non-trivial so that the eval-mode folding is exercised.
+    The pooling / embedding head (seg_1) that forward3 never uses is left out."""
+    import math
+    sd = OrderedDict()
+
+    def bn(prefix, n, gamma=1.0):
+        sd[prefix + ".weight"] = gamma * (1.0 + hash_symmetric(prefix + ".w", (n,), 0.1, seed))
+        sd[prefix + ".bias"] = _b(prefix + ".b", n, 0.05, seed)
+        sd[prefix + ".running_mean"] = _b(prefix + ".m", n, 0.05, seed)
+        sd[prefix + ".running_var"] = 1.0 + hash_symmetric(prefix + ".v", (n,), 0.2, seed)
+        sd[prefix + ".num_batches_tracked"] = torch.tensor(100, dtype=torch.long)
+
+    def conv(name, cout, cin, k, gain=1.0, bias=False):
+        sd[name + ".weight"] = _w(name, (cout, cin, k, k), cin * k * k, gain, seed)
+        if bias:
+            sd[name + ".bias"] = _b(name + ".bias", cout, 0.05, seed)
+
+    def aff(prefix, ch):
+        inter = ch // 4
+        conv(prefix + ".local_att.0", inter, 2 * ch, 1, 1.0, True)
+        bn(prefix + ".local_att.1", inter)
+        conv(prefix + ".local_att.3", ch, inter, 1, 1.0, True)
+        bn(prefix + ".local_att.4", ch)
+
+    conv("conv1", m_channels, 1, 3, 1.0)
+    bn("bn1", m_channels)
+    in_planes = m_channels
+    for li, (planes, nb, stride) in enumerate(zip((m_channels, 2 * m_channels, 4 * m_channels, 8 * m_channels), num_blocks, (1, 2, 2, 2)), 1):
+        width = int(math.floor(planes * (base_width / 64.0)))
+        for bi in range(nb):
+            p = f"layer{li}.{bi}"
+            st = stride if bi == 0 else 1
+            conv(p + ".conv1", width * scale, in_planes, 1)
+            bn(p + ".bn1", width * scale)
+            for i in range(scale):
+                conv(p + f".convs.{i}", width, width, 3)
+                bn(p + f".bns.{i}", width)
+            if li >= 3:
+                for j in range(scale - 1):
+                    aff(p + f".fuse_models.{j}", width)
+            conv(p + ".conv3", planes * expansion, width * scale, 1, 0.7)
+            bn(p + ".bn3", planes * expansion)
+            if st != 1 or in_planes != planes * expansion:
+                conv(p + ".shortcut.0", planes * expansion, in_planes, 1, 0.8)
+                bn(p + ".shortcut.1", planes * expansion)
+            in_planes = planes * expansion
+    conv("layer3_ds", 8 * m_channels * expansion, 4 * m_channels * expansion, 3, 1.0)
+    aff("fuse34", 8 * m_channels * expansion)
+    return sd
+
+
 def make_waveform(n: int, seed: int = 0, sr: int = 16000) -> torch.Tensor:
     """a speech-like test signal in [-0.5, 0.5]: a few amplitude-modulated partials + hash noise, [n] fp32"""
     t = np.arange(n, dtype=np.float64) / sr

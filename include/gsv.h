@@ -255,6 +255,7 @@ typedef struct {
   int Z; long long xz, wz, yz; int ldx, ldw, ldy;
   const float* gate;   /* optional per-output-channel gate: y = ((W x + b) * gate + res) * scale */
   int bz;              /* grouped convs (Z > 1): element stride of bias between slices (0 = one bias shared by all) */
+  long long rz; int ldr; /* residual: element stride between slices (0 = yz) and leading dim (0 = ldy) */
 } gsv_conv_desc;
 /* fused softmax attention of the DiT blocks alone (fp16, head dim 64): qkv [dev] f16 [T][3*heads*64] (q | k | v column
  * blocks), vt_scratch [dev] heads*64*ceil32(T) halfs, out [dev] f16 [T][heads*64] */
@@ -279,11 +280,16 @@ int gsv_op_layernorm(const void* x, const void* res, const float* gamma, const f
  *  gsv_op_frame: out[t][k] = x[reflect(t*hop + k - pad)], k < frame_len, zero up to ld; x [dev] fp32 [n]; out [T_out][ld] of dtype
  *    (torch.stft's reflect framing, reference module/mel_processing.py:55-71; pad = 0: the operand of a strided Conv1d(1, C, k))
  *  gsv_op_magnitude: re_im [dev] fp32 [T][2*bins] (re | im) -> sqrt(re^2 + im^2 + eps) (:73) as spec [dev] fp32 [bins][T]
- *    (frame_ld = 0), or frame-major [T][frame_ld] zero-filled beyond bins (the operand of the mel-filterbank GEMM, :138-140)
+ *    (frame_ld = 0), or frame-major [T][frame_ld] zero-filled beyond bins (the operand of the mel-filterbank GEMM, :138-140);
+ *    eps < 0: the power spectrum re^2 + im^2 (Kaldi fbank use_power, eres2net/kaldi.py:612-614)
  *  gsv_op_channel_norm: channels-last [T][C]: per-channel mean / biased variance over T, affine, activation (ACT codes of
- *    gsv_conv_desc.post_act) -- torch.nn.GroupNorm(C, C) of the HuBERT feature extractor; scratch [dev] 128*C floats */
+ *    gsv_conv_desc.post_act) -- torch.nn.GroupNorm(C, C) of the HuBERT feature extractor; scratch [dev] 128*C floats
+ *  gsv_op_aff_mix: out = x (1 + t) + y (1 - t) over n fp32 elements (eres2net/fusion.py:22-27, t = tanh of the attention branch)
+ *  gsv_op_time_mean: x [dev] fp32 [T][ld] -> out[ld] = mean over T (ERes2NetV2.forward3, eres2net/ERes2NetV2.py:258) */
 int gsv_op_frame(const float* x, int n, int frame_len, int hop, int pad, int ld, int T_out, void* out, int dtype, gsv_stream_t stream);
 int gsv_op_magnitude(const float* re_im, int T, int bins, float eps, int frame_ld, float* spec, gsv_stream_t stream);
+int gsv_op_aff_mix(const float* x, const float* y, const float* t, long long n, float* out, gsv_stream_t stream);
+int gsv_op_time_mean(const float* x, int T, int ld, float* out, gsv_stream_t stream);
 int gsv_op_channel_norm(const void* x, int T, int C, const float* gamma, const float* beta, float eps, int act, float* scratch,
                         void* y, int dtype, gsv_stream_t stream);
 /* sampling kernel alone: logits [dev] fp32 [B][vocab], prev [dev] int32 [B][prev_len], noise [dev]

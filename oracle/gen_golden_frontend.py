@@ -14,6 +14,9 @@
                               v4 `mel_fn` parameters (TTS_infer_pack/TTS.py:67-92) on seeded waveforms; librosa is not
                               installed, so the module's `librosa_mel_fn` is oracle/mel_filterbank.mel here (the filterbank
                               matrix itself is "parity unpinned", the STFT / magnitude / matmul / log-clamp around it is pinned)
+  tests/golden/sv_eres2net.npz  the reference's Kaldi fbank (eres2net/kaldi.py, pure torch) and ERes2NetV2(baseWidth=24, scale=4,
+                              expansion=4).forward3 (eres2net/ERes2NetV2.py) -- what SV.compute_embedding3 (sv.py:24-32) runs --
+                              on gsv.synthetic.make_eres2net_state_dict weights and a seeded 3 s waveform at 16 kHz
 
     python oracle/gen_golden_frontend.py
 """
@@ -32,6 +35,7 @@ from oracle import ref_import  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 SPEC_CASES = {"spec_32k_half_s": (16000, 0), "spec_32k_ragged": (22001, 1), "spec_short": (1500, 2)}
 BERT_TEXT = "你好，我是小明。今天天气不错，我们一起去公园散步吧！"
+SV_N = 48000             # 3 s at 16 kHz -> 298 fbank frames
 HUBERT_N = 20800          # 1.3 s at 16 kHz -> 64 frames
 
 
@@ -85,6 +89,19 @@ def main():
         m = mp.mel_spectrogram_torch(y, **kw)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), mel=m.numpy().astype(np.float32))
         print(name, tuple(m.shape), float(m.min()), float(m.max()))
+    sys.path.insert(0, os.path.join(ref_import.REF_ROOT, "GPT_SoVITS", "eres2net"))
+    import kaldi as Kaldi
+    from ERes2NetV2 import ERes2NetV2
+    em = ERes2NetV2(baseWidth=24, scale=4, expansion=4).eval()
+    r = em.load_state_dict(S.make_eres2net_state_dict(seed=0), strict=False)
+    assert not r.unexpected_keys and all(k.startswith("seg_1.") for k in r.missing_keys), r      # forward3 never uses the head
+    wav = S.make_waveform(SV_N, 5).unsqueeze(0)
+    with torch.no_grad():
+        feat = torch.stack([Kaldi.fbank(w.unsqueeze(0), num_mel_bins=80, sample_frequency=16000, dither=0) for w in wav])
+        emb = em.forward3(feat.clone())
+    np.savez_compressed(os.path.join(GOLD, "sv_eres2net.npz"), fbank=feat[0].numpy().astype(np.float32),
+                        emb=emb[0].numpy().astype(np.float32))
+    print("sv", tuple(feat.shape), tuple(emb.shape), float(emb.abs().mean()))
 
 
 if __name__ == "__main__":

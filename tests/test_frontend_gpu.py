@@ -109,6 +109,18 @@ def test_set_ref_audio_end_to_end(tmp_path):
     out = list(tts.run({"segments": segs, "batch_size": 2, "top_k": 1, "seed": 0}))
     sr, audio = out[-1]
     assert sr == 32000 and audio.dtype == np.int16 and audio.size == 2 * (20 * 1280 + int(32000 * 0.3))
+    # auxiliary references (TTS.py:1098-1113): spectrograms appended after the main one, cached by path set, missing files skipped
+    aux = str(tmp_path / "aux.wav")
+    _write_wav(aux, S.make_waveform(2 * 32000, 9, sr=32000).numpy(), 32000)
+    req = {"segments": segs, "batch_size": 2, "top_k": 1, "seed": 0, "aux_ref_audio_paths": [aux, str(tmp_path / "missing.wav")]}
+    sr, audio2 = list(tts.run(req))[-1]
+    assert len(tts.prompt_cache["refer_spec"]) == 2 and tuple(tts.prompt_cache["refer_spec"][1][0].shape) == (1, 1025, 100)
+    assert audio2.shape == audio.shape and not np.array_equal(audio2, audio)          # the style vector changed
+    kept = tts.prompt_cache["refer_spec"][1][0]
+    list(tts.run(req))
+    assert tts.prompt_cache["refer_spec"][1][0] is kept                              # same path set: nothing recomputed
+    sr, audio3 = list(tts.run(dict(req, aux_ref_audio_paths=[])))[-1]
+    assert len(tts.prompt_cache["refer_spec"]) == 1 and np.array_equal(audio3, audio)
 
 
 def test_bert_feature_matches_transformers_model():
@@ -160,3 +172,83 @@ def test_zh_text_through_preprocessor_with_bert_engine():
         assert sg["bert_features"].shape == (1024, len(sg["phones"])) and bool(sg["bert_features"].any())
     f = segs[0]["bert_features"]
     assert torch.equal(f[:, 0], f[:, 1]) and not torch.equal(f[:, 1], f[:, 2])      # two phones of one character share its vector
+
+
+def test_kaldi_fbank_matches_reference():
+    """N4: Kaldi fbank with the frame pre-processing folded into the DFT basis vs the reference's eres2net/kaldi.py (fp32 torch):
+    298 frames x 80 log-energies in [-13.4, 1.2]; max-abs <= 2e-3, rms <= 1e-4; short input -> empty result (kaldi.py:65)."""
+    from gsv import synthetic as S
+    from gsv.eres2net import kaldi as Kaldi
+    g = load_golden("sv_eres2net")["fbank"]
+    wav = S.make_waveform(48000, 5).unsqueeze(0).to(DEV)
+    fb = Kaldi.fbank(wav, num_mel_bins=80, sample_frequency=16000, dither=0)
+    o = fb.cpu().numpy()
+    assert o.shape == g.shape == (298, 80)
+    err, rms = np.abs(o - g).max(), np.sqrt(((o - g) ** 2).mean())
+    print(f"[frontend] kaldi fbank: max-abs {err:.2e}, rms {rms:.2e}")
+    assert err <= 2e-3 and rms <= 1e-4
+    assert Kaldi.fbank(wav[:, :300], num_mel_bins=80).shape == (0, 80)
+    with pytest.raises(NotImplementedError):
+        Kaldi.fbank(wav, num_mel_bins=80, dither=1.0)
+
+
+def test_eres2netv2_embedding_matches_reference():
+    """N4: SV.compute_embedding3 (fbank -> ERes2NetV2 w24 s4 e4 forward3, fp32 engine, BatchNorm folded) vs the reference classes
+    on the same synthetic weights: 20480 values of mean |.| 2.0; relative rms <= 1e-4, max-abs <= 2e-3.  Also block by block
+    against the oracle's taps on a shorter input."""
+    from gsv import synthetic as S
+    from gsv.sv import SV
+    from oracle import sv_oracle as so
+    g = load_golden("sv_eres2net")["emb"]
+    sd = S.make_eres2net_state_dict(seed=0)
+    sv = SV(DEV, False, state_dict=sd)
+    wav = S.make_waveform(48000, 5).unsqueeze(0).to(DEV)
+    emb = sv.compute_embedding3(wav)
+    assert tuple(emb.shape) == (1, 20480) and emb.dtype == torch.float32
+    o = emb[0].cpu().numpy()
+    rel, err = np.sqrt(((o - g) ** 2).mean() / (g ** 2).mean()), np.abs(o - g).max()
+    print(f"[frontend] ERes2NetV2 embedding: relative rms {rel:.2e}, max-abs {err:.2e}")
+    assert rel <= 1e-4 and err <= 2e-3
+    assert SV(DEV, True, state_dict=sd).compute_embedding3(wav.half()).dtype == torch.float16
+    # odd frame count (stride-2 stages round up) and a batch of two
+    wav2 = torch.stack([S.make_waveform(16000 + 570, 6), S.make_waveform(16000 + 570, 7)])
+    ref = so.compute_embedding3(sd, wav2)
+    out = sv.compute_embedding3(wav2.to(DEV)).cpu()
+    assert out.shape == ref.shape and ((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) <= 1e-4
+
+
+def test_set_ref_audio_v2pro_computes_speaker_embedding(tmp_path):
+    """v2Pro: set_ref_audio also produces the ERes2NetV2 embedding of the (peak-normalised, 16 kHz) reference audio
+    (TTS.py:790-800, 1233-1238) and TTS.run synthesises with it; without init_sv_model() the call is refused."""
+    import copy
+    from gsv import synthetic as S
+    from gsv.TTS_infer_pack.TTS import TTS
+    from oracle import sv_oracle as so
+    cfg = copy.deepcopy(S.VITS_V2_CONFIG)
+    cfg["model"]["version"], cfg["model"]["gin_channels"] = "v2Pro", 1024
+    tts = TTS({"device": DEV, "is_half": True, "version": "v2Pro", "max_batch": 4, "max_seq": 600})
+    tts.init_t2s_weights(state={"weight": S.make_t2s_state_dict(S.T2S_V2_CONFIG, seed=0, suppress_eos=True), "config": S.T2S_V2_CONFIG})
+    tts.init_vits_weights(state={"weight": S.make_vits_state_dict(cfg, seed=0), "config": cfg})
+    tts.init_cnhuhbert_weights(state_dict=S.make_hubert_state_dict(seed=0))
+    wav = S.make_waveform(3 * 32000 + 777, 3, sr=32000).numpy()
+    p = str(tmp_path / "ref.wav")
+    _write_wav(p, wav, 32000)
+    with pytest.raises(RuntimeError):
+        tts.set_ref_audio(p)                                         # no SV model yet
+    sd = S.make_eres2net_state_dict(seed=0)
+    tts.init_sv_model(state_dict=sd)
+    tts.set_ref_audio(p)
+    spec, audio16k = tts.prompt_cache["refer_spec"][0]
+    emb = tts.prompt_cache["sv_emb"][0]
+    assert audio16k.dtype == torch.float16 and tuple(emb.shape) == (1, 20480) and emb.dtype == torch.float16
+    ref = so.compute_embedding3(sd, audio16k.float().cpu())
+    rel = float(((emb.float().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()))
+    assert rel <= 2e-3                                               # the fp16 cast of the result dominates
+    utt = S.make_utterances(2)
+    tts.prompt_cache["phones"] = utt["prompt_phones"]
+    tts.prompt_cache["bert_features"] = torch.zeros(1024, len(utt["prompt_phones"]))
+    segs = [{"phones": it["phones"], "bert_features": torch.zeros(1024, len(it["phones"])), "norm_text": it["norm_text"]}
+            for it in utt["items"]]
+    tts.configs.max_sec = 0.4
+    sr, audio = list(tts.run({"segments": segs, "batch_size": 2, "top_k": 1, "seed": 0}))[-1]
+    assert sr == 32000 and audio.dtype == np.int16 and audio.size == 2 * (20 * 1280 + int(32000 * 0.3)) and np.abs(audio).max() > 0

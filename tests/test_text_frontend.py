@@ -164,3 +164,18 @@ def test_mel_oracle_reproduces_reference_goldens():
         y = S.make_waveform(n, seed, sr=sr).unsqueeze(0)
         o = omf.mel_spectrogram(y, n_fft, 100, sr, hop, n_fft, 0, None).numpy()
         assert o.shape == g.shape and np.abs(o - g).max() <= 1e-5
+
+
+def test_sv_oracle_reproduces_reference_golden():
+    """oracle/sv_oracle.py (Kaldi fbank + ERes2NetV2.forward3 restated) against tests/golden/sv_eres2net.npz (the reference's own
+    eres2net/kaldi.py and ERes2NetV2 classes run in the build container on the synthetic weights)"""
+    import os
+    import numpy as np
+    import torch
+    from gsv import synthetic as S
+    from oracle import sv_oracle as so
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sv_eres2net.npz"))
+    fb = so.fbank(S.make_waveform(48000, 5))
+    assert fb.shape == (298, 80) and np.abs(fb.numpy() - g["fbank"]).max() <= 5e-4
+    emb = so.ERes2NetV2Oracle(S.make_eres2net_state_dict(seed=0)).forward3(torch.from_numpy(g["fbank"]).unsqueeze(0))
+    assert emb.shape == (1, 20480) and np.abs(emb[0].numpy() - g["emb"]).max() <= 1e-4
