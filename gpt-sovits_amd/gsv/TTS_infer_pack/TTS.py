@@ -226,9 +226,23 @@ class TTS:
         m.load_state_dict(state["weight"])
         self.t2s_model = m
 
-    def init_vits_weights(self, weights_path: Optional[str] = None, state: Optional[dict] = None):
+    def init_vits_weights(self, weights_path: Optional[str] = None, state: Optional[dict] = None, base_state: Optional[dict] = None):
+        """reference TTS.py:484-582.  A v3 / v4 LoRA checkpoint (version code 03 / 04, or a `state` carrying "lora_rank") is merged
+        into the base model's weights first (`process_ckpt.merge_lora_v3`); the base comes from `base_state` or from the
+        configured pretrained path of that version, and a missing base raises FileExistsError like the reference (:491-493)."""
+        from ..process_ckpt import get_sovits_version_from_path_fast, merge_lora_v3
         if state is None:
             state = load_sovits_new(weights_path)
+        if_lora = "lora_rank" in state
+        if weights_path is not None and not if_lora:
+            if_lora = bool(get_sovits_version_from_path_fast(weights_path)[2])
+        if if_lora:
+            if base_state is None:
+                path_sovits = self.configs.default_configs[self.configs.version]["vits_weights_path"]
+                if not os.path.exists(path_sovits):
+                    raise FileExistsError(f"{path_sovits}: SoVITS {self.configs.version} base model missing, cannot load the LoRA weights")
+                base_state = load_sovits_new(path_sovits)
+            state = dict(state, weight=merge_lora_v3(base_state["weight"], state["weight"], int(state["lora_rank"])))
         self._vits_state = state
         hps = state["config"]
         d, mcfg = hps["data"], dict(hps["model"])

@@ -65,3 +65,47 @@ def my_save2(fea, path: str, model_version: str) -> None:
     data = bio.getvalue()
     with open(path, "wb") as f:
         f.write(model_version2byte[model_version] + data[2:])
+
+
+_PEFT_PREFIX = "cfm.base_model.model."
+
+
+def merge_lora_v3(base_weight: dict, lora_weight: dict, lora_rank: int, lora_alpha: int = None) -> dict:
+    """What the reference does with a v3 / v4 LoRA checkpoint (TTS_infer_pack/TTS.py:556-572): load the base model, wrap
+    `cfm` with peft's LoraConfig(target_modules=[to_k, to_q, to_v, to_out.0], r=rank, lora_alpha=rank), load the LoRA state
+    dict (strict=False) and `merge_and_unload()` -- restated on the state dict, without peft (not installed here; "parity
+    unpinned" against the package, the arithmetic is peft's documented merge):
+        W' = W + (lora_alpha / r) * lora_B @ lora_A          per targeted Linear, in fp32.
+    Keys: the wrapped model names parameters `cfm.base_model.model.<path>.lora_A.default.weight` / `lora_B.default.weight` and
+    the frozen original `<path>.base_layer.weight`; anything else in the LoRA file that names a base parameter overrides it."""
+    alpha = lora_rank if lora_alpha is None else lora_alpha
+    out = dict(base_weight)
+    merged = 0
+    for k, a in lora_weight.items():
+        if k.endswith(".lora_A.default.weight") or k.endswith(".lora_A.weight"):
+            stem = k[:k.index(".lora_A.")]
+            kb = k.replace(".lora_A.", ".lora_B.")
+            if kb not in lora_weight:
+                raise KeyError(f"{k} has no matching lora_B")
+            b = lora_weight[kb]
+            if a.shape[0] != lora_rank or b.shape[1] != lora_rank:
+                raise ValueError(f"{k}: rank {a.shape[0]} / {b.shape[1]} does not match lora_rank {lora_rank}")
+            path = stem[len(_PEFT_PREFIX):] if stem.startswith(_PEFT_PREFIX) else stem
+            target = ("cfm." + path if stem.startswith(_PEFT_PREFIX) else path) + ".weight"
+            if target not in out:
+                raise KeyError(f"LoRA target {target} is not a parameter of the base model")
+            w = out[target]
+            out[target] = (w.float() + (alpha / lora_rank) * (b.float() @ a.float())).to(w.dtype)
+            merged += 1
+        elif ".lora_B." in k:
+            continue
+        else:
+            kk = k
+            if kk.startswith(_PEFT_PREFIX):
+                kk = "cfm." + kk[len(_PEFT_PREFIX):]
+            kk = kk.replace(".base_layer.", ".")
+            if kk in out:
+                out[kk] = lora_weight[k]
+    if merged == 0:
+        raise ValueError("no lora_A / lora_B pairs in the LoRA checkpoint")
+    return out

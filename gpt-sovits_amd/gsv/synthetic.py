@@ -526,6 +526,18 @@ def make_vits_v3_state_dict(config=None, seed: int = 0, dit_cfg=None) -> "Ordere
 # --------------------------------------------------------------------------
 # HuBERT-base (reference feature_extractor/cnhubert.py: transformers.HubertModel, HubertConfig defaults)
 # --------------------------------------------------------------------------
+def make_lora_state_dict(base: dict, rank: int = 4, seed: int = 3) -> "OrderedDict[str, torch.Tensor]":
+    """a v3 / v4 LoRA checkpoint's `weight` as peft names it for `cfm` wrapped with target_modules [to_q, to_k, to_v, to_out.0]
+    (reference TTS.py:561-567): lora_A [rank, in] / lora_B [out, rank] per targeted Linear of the base state dict, fp16"""
+    lw = OrderedDict()
+    for k, w in base.items():
+        if k.startswith("cfm.") and any(k.endswith(t + ".weight") for t in ("to_q", "to_k", "to_v", "to_out.0")):
+            stem = "cfm.base_model.model." + k[len("cfm."):-len(".weight")]
+            lw[stem + ".lora_A.default.weight"] = hash_symmetric(stem + "A", (rank, w.shape[1]), 0.2, seed).half()
+            lw[stem + ".lora_B.default.weight"] = hash_symmetric(stem + "B", (w.shape[0], rank), 0.2, seed).half()
+    return lw
+
+
 def make_hubert_state_dict(seed: int = 0, layers: int = 12, hidden: int = 768, ffn: int = 3072, conv_dim: int = 512,
                            pos_kernel: int = 128, pos_groups: int = 16) -> "OrderedDict[str, torch.Tensor]":
     """fp32 state dict with transformers.HubertModel's key names (weight-normed positional conv as

@@ -122,3 +122,34 @@ def test_streaming_framing_and_tts_handle():
         assert code == 400 and "ffmpeg" in body["Exception"]
     app = wire.create_app(Fake())                        # the reference's routes exist
     assert {r.path for r in app.routes if hasattr(r, "methods")} >= {"/tts"}
+
+
+def test_lora_merge_arithmetic_and_errors():
+    """v3 / v4 LoRA checkpoints (TTS.py:556-572): W' = W + (alpha / r) B A on to_q / to_k / to_v / to_out.0 of every DiT block,
+    nothing else touched; peft is not installed, so this pins the restated arithmetic, not the package ("parity unpinned")."""
+    from gsv import synthetic as S
+    vcfg = S.small_vits_config()
+    vcfg["model"]["inter_channels"] = vcfg["model"]["hidden_channels"]
+    dit = S.small_dit_config()
+    dit["text_dim"] = 512
+    base = S.make_vits_v3_state_dict(vcfg, seed=12, dit_cfg=dit)
+    lw = S.make_lora_state_dict(base, rank=4, seed=3)
+    n_targets = len(lw) // 2
+    assert n_targets == 4 * dit["depth"]
+    merged = pc.merge_lora_v3(base, lw, 4)
+    changed = [k for k in base if not torch.equal(base[k], merged[k])]
+    assert len(changed) == n_targets and set(merged) == set(base)
+    k = "cfm.estimator.transformer_blocks.0.attn.to_q.weight"
+    a = lw["cfm.base_model.model.estimator.transformer_blocks.0.attn.to_q.lora_A.default.weight"].float()
+    b = lw["cfm.base_model.model.estimator.transformer_blocks.0.attn.to_q.lora_B.default.weight"].float()
+    assert torch.allclose(merged[k].float(), base[k].float() + b @ a, atol=1e-6) and merged[k].dtype == base[k].dtype
+    assert torch.allclose(pc.merge_lora_v3(base, lw, 4, lora_alpha=8)[k].float(), base[k].float() + 2 * (b @ a), atol=1e-6)
+    with pytest.raises(ValueError):
+        pc.merge_lora_v3(base, lw, 8)                                   # rank in the file differs from lora_rank
+    with pytest.raises(ValueError):
+        pc.merge_lora_v3(base, {"enc_p.ssl_proj.weight": base["enc_p.ssl_proj.weight"]}, 4)     # no LoRA pairs at all
+    bad = dict(lw)
+    bad["cfm.base_model.model.estimator.nowhere.to_q.lora_A.default.weight"] = a
+    bad["cfm.base_model.model.estimator.nowhere.to_q.lora_B.default.weight"] = b
+    with pytest.raises(KeyError):
+        pc.merge_lora_v3(base, bad, 4)

@@ -170,3 +170,28 @@ def test_ref_mel_from_raw_audio_feeds_the_prompt(version):
     want = ref[:, :, :full]
     want = want[:, :, -T_ref:] if want.shape[2] > T_ref else want
     assert (mel2.float().cpu() - want).abs().max() <= 5e-4
+
+
+def test_lora_checkpoint_is_merged_into_the_base_model():
+    """init_vits_weights with a v3 LoRA state ("lora_rank" + peft-named lora_A / lora_B, TTS.py:556-572): the engine is built from
+    W + B A -- same CFM output as an engine given the merged weights directly, different from the base model's; a missing base
+    model raises FileExistsError (TTS.py:491-493)."""
+    from gsv import process_ckpt as pc
+    tts, _, (vcfg, vsd, dit), _ = _build("v3")
+    lw = S.make_lora_state_dict(vsd, rank=4, seed=3)
+    merged = pc.merge_lora_v3(vsd, lw, 4)
+
+    def cfm_out(t):
+        fea = S.hash_symmetric("lora_fea", (1, 40, 512), 1.0, 1).to(DEV)
+        mel = S.hash_symmetric("lora_mel", (1, 100, 16), 1.0, 2).to(DEV)
+        return t.vits_model.cfm.inference(fea, torch.LongTensor([40]).to(DEV), mel, 2, inference_cfg_rate=0,
+                                          noise=S.hash_normal("lora_noise", (1, 100, 40), 1).to(DEV)).float().cpu()
+
+    base_out = cfm_out(tts)
+    tts.init_vits_weights(state={"weight": lw, "config": vcfg, "lora_rank": 4}, base_state={"weight": vsd, "config": vcfg})
+    lora_out = cfm_out(tts)
+    tts.init_vits_weights(state={"weight": merged, "config": vcfg})
+    want = cfm_out(tts)
+    assert torch.equal(lora_out, want) and (lora_out - base_out).abs().max() > 1e-3
+    with pytest.raises(FileExistsError):
+        tts.init_vits_weights(state={"weight": lw, "config": vcfg, "lora_rank": 4})
