@@ -143,6 +143,7 @@ struct Ctx {
   gu64* hop;
   gu32* err;
   int hint_miss16;              // hint phase ends when at most this many 16ths of the polled lines are still missing
+  int hint_pipe;                // two hint polls in flight (GSV_MEGA_HINT bit 4)
   unsigned long long* prof;     // this wave's 32 stamp slots or null
   bool prof_on;
 };
@@ -192,23 +193,44 @@ __device__ __forceinline__ bool sweep2(const Ctx& c, gu64* g0, gu64* g1, int nva
   // polling by 4 waves x 256 CUs was ~8 TB/s of fabric traffic by itself.
   if (hint) {
     const int nlines = (nvalid + 15) >> 4;
-    for (unsigned spins = 0;; ++spins) {
-      int miss = 0;
-      for (int l0 = 0; l0 < nlines; l0 += 64) {
-        const int ln = l0 + c.lane;
-        if (ln < nlines) {
-          const int i = min(ln * 16 + 15, nvalid - 1);
-          miss += (unsigned)(gload(g0 + i) >> 32) != epoch;
-          if (g1) miss += (unsigned)(gload(g1 + i) >> 32) != epoch;
-        }
+    constexpr int NP = (N + 15) / 16;                     // hint loads per lane and row (64 lines each)
+    // Two polls are kept in flight, half a round trip apart: a poll costs ~1 us of sc1 latency, so one at a time notices an
+    // arrival on average half a microsecond late; c.hint_pipe = 0 restores the single poll (A/B switch GSV_MEGA_HINT bit 4).
+    u64 pa[2 * NP], pb[2 * NP];
+    auto issue = [&](u64 (&h)[2 * NP]) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int ln = j * 64 + c.lane;
+        const int i = min(min(ln, nlines - 1) * 16 + 15, nvalid - 1);
+        h[2 * j] = gload(g0 + i);
+        h[2 * j + 1] = g1 ? gload(g1 + i) : ((u64)epoch << 32);
       }
+    };
+    auto landed = [&](const u64 (&h)[2 * NP]) {
+      int miss = 0;
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+        miss += ((unsigned)(h[2 * j] >> 32) != epoch) + ((unsigned)(h[2 * j + 1] >> 32) != epoch);
       // most lines there: the stragglers are at most one poll away, go on with full passes (one round trip fewer at the end)
-      if (__popcll(__ballot(miss != 0)) * 16 <= nlines * c.hint_miss16) break;
-      if (spins > SPIN_MAX || *st_abort(c) || (spins & 1023u) == 1023u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
+      return __popcll(__ballot(miss != 0)) * 16 <= nlines * c.hint_miss16;
+    };
+    issue(pa);
+    if (c.hint_pipe) __builtin_amdgcn_s_sleep(16);        // ~0.4 us: half a poll round trip
+    for (unsigned spins = 0;; spins += 2) {
+      if (c.hint_pipe) {
+        issue(pb);
+        if (landed(pa)) break;
+        issue(pa);
+        if (landed(pb)) break;
+      } else {
+        if (landed(pa)) break;
+        if (spins < 16) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
+        issue(pa);
+      }
+      if (spins > SPIN_MAX || *st_abort(c) || (spins & 1022u) == 1022u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
         mega_fail(c, epoch, code | 0x100u);
         return false;
       }
-      if (spins < 8) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
     }
   }
   for (unsigned spins = 0;; ++spins) {
@@ -344,35 +366,42 @@ __device__ __forceinline__ void attention_part(const MegaArgs& a, const Ctx& q, 
   const unsigned char* vimg = smem + L_KV + (ro * 2 + 1) * KV_CAP * 64;
   const int n_img = min(n_old, KV_CAP);
   constexpr int NT = KV_CAP / (16 * NW);               // image keys per lane
+  // All 2 NT LDS reads are issued before the first use: taken one at a time (what the compiler emits when loads and uses
+  // alternate) each costs a full LDS round trip, 2 NT + 2 of them in a row were ~2.5 us of the layer (in-kernel stamps).
+  h8 kk[NT], vv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) kk[t] = *(const h8*)(kimg + ((NW * t + hq) * 16 + slot) * 64 + part * 16);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) vv[t] = *(const h8*)(vimg + ((NW * t + hq) * 16 + slot) * 64 + part * 16);
+  const h8 k_own = *(const h8*)(qkv_s + HD + part * 8), v_own = *(const h8*)(qkv_s + 2 * HD + part * 8);
+  asm volatile("" ::: "memory");                       // keep the reads above the arithmetic
   float sc[NT + 1];
   float m = -INFINITY;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int j = (NW * t + hq) * 16 + slot;
-    const h8 kk = *(const h8*)(kimg + min(j, KV_CAP - 1) * 64 + part * 16);
-    const float v = score(kk);
+    const float v = score(kk[t]);
     sc[t] = j < n_img ? v : -INFINITY;
     m = fmaxf(m, sc[t]);
   }
   {                                                    // this step's own key: wave hq == 0, key slot 0
-    const h8 kk = *(const h8*)(qkv_s + HD + part * 8);
-    const float v = score(kk);
+    const float v = score(k_own);
     sc[NT] = (rv && hq == 0 && slot == 0) ? v : -INFINITY;
     m = fmaxf(m, sc[NT]);
   }
+  // branch-free second pass: a masked key has p = exp(-inf) = 0 and its V is finite (the LDS image is zeroed at kernel start,
+  // the K/V arena at creation: unwritten positions hold zeros or stale finite values), so 0 * V adds nothing
+  const float mz = m == -INFINITY ? 0.f : m;
   float lsum = 0.f, acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
 #pragma unroll
   for (int t = 0; t <= NT; ++t) {
-    const int j = (NW * t + hq) * 16 + slot;
-    const h8 vv = t < NT ? *(const h8*)(vimg + min(j, KV_CAP - 1) * 64 + part * 16) : *(const h8*)(qkv_s + 2 * HD + part * 8);
-    if (sc[t] != -INFINITY) {                          // masked keys may hold anything (unwritten image tail): never 0 * NaN
-      const float p = __expf(sc[t] - m);
-      lsum += p;
+    const h8 v8 = t < NT ? vv[t < NT ? t : 0] : v_own;
+    const float p = __expf(sc[t] - mz);
+    lsum += p;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] += p * (float)vv[i];
-    }
+    for (int i = 0; i < 8; ++i) acc[i] += p * (float)v8[i];
   }
   if (n_old > KV_CAP) {                                // long rows: the tail comes straight from HBM (online update)
     const _Float16* kvb = a.kv + ((size_t)(q.group + MG_GROUPS * r) * NH + q.head) * (size_t)a.smax * HD + part * 8;
@@ -709,10 +738,10 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
           const int task = q.tid_c + 256 * it, tile = task >> 6, ln = task & 63;
           const int r = ln & 15;
           if (tile >= 6 || r >= R || (r & 1) != q.half) continue;
-          f4 v = red[(0 * 6 + tile) * 64 + ln];
-          v += red[(1 * 6 + tile) * 64 + ln];
-          v += red[(2 * 6 + tile) * 64 + ln];
-          v += red[(3 * 6 + tile) * 64 + ln];
+          const f4 v0 = red[(0 * 6 + tile) * 64 + ln], v1 = red[(1 * 6 + tile) * 64 + ln], v2 = red[(2 * 6 + tile) * 64 + ln],
+                   v3 = red[(3 * 6 + tile) * 64 + ln];
+          f4 v = v0;
+          v += v1; v += v2; v += v3;
           v += p1_bias[it];
           const int ro = r >> 1, which = tile >> 1, e = 16 * (tile & 1) + 4 * (ln >> 4);
           const h4 ov = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
@@ -730,7 +759,11 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
       MG_STAMP(q, 7);
       attention_part<2>(a, q, l, q.cw);
       MG_STAMP(q, 8);
-      MG_BAR();                                                          // B4
+      // the partials of a row's two waves meet through LDS: a compute-only barrier, so that the publish below does not wait
+      // for the comm waves, which sit at B4 until their K/V loads of the next layer have landed (~3.4 us after issue: 20 MB per
+      // layer over all CUs, i.e. HBM-bound; that burst, not the arithmetic, is what P1 takes -- A/B of faster arithmetic: no change)
+      compute_barrier(q, cgen);
+      if (*st_abort(q)) return;
       MG_STAMP(q, 9);
       if (q.cw == 0) {
         // combine the 2 waves of each own row; lane = ro * 32 + e
@@ -758,6 +791,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         if (r < R && !(e & 1)) gstore(q.hop + HOP_B + r * 256 + (q.head * HD + e) / 2, ep0 + 4 * l + 2, pack_h2(o, o2));
       }
       MG_STAMP(q, 10);
+      MG_BAR();                                                          // B4: the attention has released the K/V image
       relaunder(q);
       // ================= P2: out-projection columns [16 member, +16) + bias + residual -> y1
       f4 p_bias = *(const f4*)(lp + FP_OUTB + 16 * q.member + 4 * (q.lane >> 4));
@@ -774,10 +808,12 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         const f4* red = (const f4*)(smem + L_RED);
         const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
         if (r < R) {
-          f4 v = red[q.lane];
-          v += red[64 + q.lane]; v += red[128 + q.lane]; v += red[192 + q.lane];
+          const f4 v0 = red[q.lane], v1 = red[64 + q.lane], v2 = red[128 + q.lane], v3 = red[192 + q.lane];
+          const f4 xr = *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
+          f4 v = v0;
+          v += v1; v += v2; v += v3;
           v += p_bias;
-          v += *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
+          v += xr;
           *(f4*)((float*)(smem + L_STAGE) + r * 16 + 4 * (q.lane >> 4)) = v;
         }
         // transposed through LDS (same wave): lane = row * 16 + column, so each row's 16 granules = one 128-B line
@@ -808,8 +844,10 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) {
             const int tile = 2 * q.cw + tt;
-            f4 v = red[(0 * 4 + tile) * 64 + q.lane];
-            v += red[(1 * 4 + tile) * 64 + q.lane]; v += red[(2 * 4 + tile) * 64 + q.lane]; v += red[(3 * 4 + tile) * 64 + q.lane];
+            const f4 v0 = red[(0 * 4 + tile) * 64 + q.lane], v1 = red[(1 * 4 + tile) * 64 + q.lane],
+                     v2 = red[(2 * 4 + tile) * 64 + q.lane], v3 = red[(3 * 4 + tile) * 64 + q.lane];
+            f4 v = v0;
+            v += v1; v += v2; v += v3;
             v += tt == 0 ? p_bias : p_bias2;
             const int w0 = r * 16 + tt * 8 + 2 * (q.lane >> 4);
             stage[w0] = pack_h2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
@@ -851,11 +889,17 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         const f4* red = (const f4*)(smem + L_RED);
         const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
         if (r < R) {
-          f4 v = red[q.lane];
+          // all 17 LDS reads first (one at a time each costs a full LDS round trip), then the sum in chunk order
+          f4 part[16];
 #pragma unroll
-          for (int kc = 1; kc < 16; ++kc) v += red[kc * 64 + q.lane];
+          for (int kc = 0; kc < 16; ++kc) part[kc] = red[kc * 64 + q.lane];
+          const f4 xr = *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
+          asm volatile("" ::: "memory");
+          f4 v = part[0];
+#pragma unroll
+          for (int kc = 1; kc < 16; ++kc) v += part[kc];
           v += p_bias;
-          v += *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
+          v += xr;
           // y2 feeds hop A of the next layer, or hop A' (the logits' LayerNorm) after the last layer
           *(f4*)((float*)(smem + L_STAGE) + r * 16 + 4 * (q.lane >> 4)) = v;
         }
@@ -906,11 +950,13 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   c.prof = a.prof ? a.prof + ((size_t)blockIdx.x * 8 + c.wave) * 32 : nullptr;
   c.prof_on = false;
   c.hint_miss16 = (a.hint_mask >> 8) & 31;
+  c.hint_pipe = (a.hint_mask >> 4) & 1;
   const int lane = c.lane, R = c.R;
   const StepParams sp = *a.sp;
 
   // ---- init: zero the activation images, load the row state, build the samplers' seen-map ----
   for (int i = tid; i < L_RED / 4; i += MG_THREADS) ((unsigned*)smem)[i] = 0u;
+  for (int i = tid; i < (L_TOTAL - L_KV) / 4; i += MG_THREADS) ((unsigned*)(smem + L_KV))[i] = 0u;   // attention_part relies on finite image cells
   if (tid < 16) ((int*)(smem + L_ST))[tid] = 0;
   __syncthreads();
   if (tid < R) {

@@ -15,10 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "gpt-sovits_amd")):
     sys.path.insert(0, p)
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "mega_prof_raw.txt")
-os.environ["GSV_MEGA_PROF"] = out
+if os.environ.get("PROF_OFF") != "1":            # PROF_OFF=1: timing only (the stamps themselves cost ~15 us per step)
+    os.environ["GSV_MEGA_PROF"] = out
 
 import torch  # noqa: E402
 from gsv import synthetic as S  # noqa: E402
+if os.environ.get("GSV_LIB_PATH"):                 # A/B against another build of the library
+    from gsv import _lib
+    _lib.LIB_PATH = os.environ["GSV_LIB_PATH"]
 from gsv.AR.models.t2s_model import Text2SemanticDecoder  # noqa: E402
 
 B = int(os.environ.get("PROF_B", "32"))
@@ -34,6 +38,8 @@ for _ in range(3):
     eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
 mode, ms, steps = eng.decode_info()
 print(f"mode {mode}: {ms:.2f} ms for {steps} steps = {ms / steps * 1e3:.1f} us/step = {ms / steps * 1e3 / 24.5:.2f} us/layer")
+if os.environ.get("PROF_OFF") == "1":
+    sys.exit(0)
 rows = [l.split() for l in open(out) if not l.startswith("#")]
 COMM = ["start", "hopA+LN done", "B1", "B2", "B3", "B4", "hopB done", "B1", "B2", "hopC+LN done", "B1", "B2", "hopD done", "B1", "B2"]
 COMP = ["start", "wB issued", "B1", "P1 gemm", "B2", "reduce/append", "kv vmcnt0", "B3", "attention", "B4", "(unused)", "publish B",
