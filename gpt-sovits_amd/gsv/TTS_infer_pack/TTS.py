@@ -8,10 +8,10 @@ keys and defaults, length-bucketed batching, AR -> one time-axis-concatenated `d
 per-fragment peak normalisation, fragment silence, original-order recovery, x32768 int16 scaling,
 the error protocol (1 s of silence then re-raise) and `stop()`.
 
-What is *not* here (out of scope this round): the text front-end (G2P/BERT) and the
-reference-audio front-end (HuBERT, STFT).  `run` therefore takes either a pluggable
-`text_frontend` callable or pre-tokenised segments (`inputs["segments"]`), and the prompt is set
-with `set_prompt_cache(prompt_semantic, refer_spec, phones, bert)` instead of a wav path.
+Front-ends are separate modules this class wires together: `set_ref_audio(path)` =
+WAV -> HuBERT engine -> `extract_latent` (prompt tokens), `spectrogram_torch` (reference spectrogram), for v2Pro the ERes2NetV2
+speaker embedding, for v3 / v4 the reference mel; `run({"text": ...})` goes through `TextPreprocessor` (pluggable G2P and
+language splitter, BERT engine for zh).  Pre-tokenised `segments` and `set_prompt_cache(...)` remain as the model-level entry.
 """
 from __future__ import annotations
 
