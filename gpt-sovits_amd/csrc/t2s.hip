@@ -1186,7 +1186,9 @@ int gsv_t2s_finalize(gsv_t2s_t* h) {
         dst += ns[k];
       }
     }
-    m.hop_bytes = mega_hop_bytes();
+    m.ring = getenv("GSV_MEGA_RING") ? atoi(getenv("GSV_MEGA_RING")) : 1;           // hop buffer sets (t2s_mega.hip hop_slot); measured: 16 sets are 4 % slower than 1
+    if (m.ring < 1) m.ring = 1;
+    m.hop_bytes = mega_hop_bytes(m.ring);
     GSV_RC(dev_alloc(h, (void**)&m.hop, m.hop_bytes));
     GSV_RC(dev_alloc(h, (void**)&m.err, 64));
     GSV_HIP(hipHostMalloc((void**)&m.h_err, 64));
@@ -1522,8 +1524,11 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
       a.nsteps = budget - 1; a.map_shared = map_local ? 0 : 1;
       // bits 0-3: hops (A, B, C, D) that poll one granule per line first; bits 8-12: 16ths of the lines that may still be
       // missing when the full passes start
-      static const int hint_mask = getenv("GSV_MEGA_HINT") ? atoi(getenv("GSV_MEGA_HINT")) : (15 | (2 << 8));   // bit 4 (two polls in flight) measured 3 % slower
+      static const int hint_mask = getenv("GSV_MEGA_HINT") ? atoi(getenv("GSV_MEGA_HINT")) : (15 | (2 << 8));   // bit 4 (two polls in flight): 3 % slower; bit 5 (payload through L2, needs GSV_MEGA_RING > 1): no gain
       a.hint_mask = hint_mask;
+      a.ring = m.ring;
+      m.launch_gen = (m.launch_gen + 1) & 2047;
+      a.ep_base = m.launch_gen << 20;                       // 1500 steps x 98 hops < 2^20
       // measurement runs: GSV_MEGA_PROF=<file> dumps in-kernel shader-clock stamps of one (step, layer) for every wave
       const char* prof_path = getenv("GSV_MEGA_PROF");
       unsigned long long* d_prof = nullptr;

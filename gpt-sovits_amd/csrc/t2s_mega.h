@@ -15,6 +15,8 @@ struct MegaState {        // owned by the t2s handle
   float* fpack = nullptr;         // [n_layer][6656] fp32: qkv_b | out_b | b1 | b2 | n1w | n1b | n2w | n2b
   unsigned long long* hop = nullptr;   // hop granule buffers, all groups
   size_t hop_bytes = 0;
+  int ring = 1;                   // hop buffer sets
+  unsigned launch_gen = 0;        // bumps every launch: epochs = launch_gen << 20 + ...
   unsigned* err = nullptr;        // [4]: timeout word, epoch, block, code
   unsigned* h_err = nullptr;      // pinned host copy
   int census = -1;                // -1 not run, 0 failed (mega disabled), 1 all 256 workgroups co-resident
@@ -35,6 +37,8 @@ struct MegaArgs {
   int prof_step, prof_layer;
   int hint_mask;                  // hops that poll one granule per line before the full pass: bit 0 A, 1 B, 2 C, 3 D; bit 4: two polls in flight; bits 8-12: miss threshold
   int map_shared;                 // 1: workgroups reading the same weight slice share an XCD (default), 0: group = XCD
+  int ring;                       // hop buffer sets used round-robin over (step, layer); > 1 enables L2-shared payload reads
+  unsigned ep_base;               // launch generation << 20: epochs never repeat between launches (stale cached lines cannot match)
 };
 
 // shape gate: the persistent engine is specialised for the v1/v2 decoder
@@ -46,7 +50,7 @@ void mega_pack_layer(const float* qkv_w, const float* out_w, const float* w1, co
 void mega_pack_logits(const float* pred_w, int V, _Float16* dst);
 size_t mega_layer_pack_halfs();
 size_t mega_logits_pack_halfs();
-size_t mega_hop_bytes();
+size_t mega_hop_bytes(int ring);
 constexpr int MEGA_FP_LAYER = 6656;      // floats per layer in fpack
 
 int mega_census(hipStream_t s, unsigned* d_scratch, unsigned* h_pinned);   // 1 ok, 0 not co-resident, <0 error

@@ -140,7 +140,10 @@ struct Ctx {
   int lane, wave, cw, tid_c;
   bool comm;
   int group, member, head, half, R;
-  gu64* hop;
+  gu64* hop;                    // this group's hop buffers of the current (step, layer) ring slot
+  gu64* hop_base;               // slot 0
+  int ring, nlayer;             // ring slots; virtual layers per step (L + 1: the tail is one)
+  bool bulk_plain;              // payload read with plain (L2-allocating) loads after the sc1 hint polls
   gu32* err;
   int hint_miss16;              // hint phase ends when at most this many 16ths of the polled lines are still missing
   int hint_pipe;                // two hint polls in flight (GSV_MEGA_HINT bit 4)
@@ -232,6 +235,29 @@ __device__ __forceinline__ bool sweep2(const Ctx& c, gu64* g0, gu64* g1, int nva
         return false;
       }
     }
+  }
+  if (hint && c.bulk_plain) {
+    // every line's last granule is there: read the payload through L2 (see hop_slot); the tags are still verified
+    const gu64* p0 = g0;
+    const gu64* p1 = g1 ? g1 : g0;
+    asm volatile("" : "+v"(p0), "+v"(p1) :: "memory");
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int i = k * 64 + c.lane;
+      v0[k] = 0u; v1[k] = 0u;
+      if (i < nvalid) {
+        const u64 x = p0[i];
+        v0[k] = (unsigned)x;
+        ok &= (unsigned)(x >> 32) == epoch;
+        if (g1) {
+          const u64 y = p1[i];
+          v1[k] = (unsigned)y;
+          ok &= (unsigned)(y >> 32) == epoch;
+        }
+      }
+    }
+    if (__all(ok)) return true;
   }
   for (unsigned spins = 0;; ++spins) {
     bool ok = true;
@@ -331,6 +357,18 @@ __device__ __forceinline__ void relaunder(Ctx& q) {
   asm volatile("" : "+v"(q.lane), "+s"(cw), "+s"(member), "+s"(group));
   q.cw = cw; q.member = member; q.group = group; q.head = member >> 1; q.half = member & 1;
   q.tid_c = q.cw * 64 + q.lane;
+}
+
+// A/B option (GSV_MEGA_RING = n > 1, GSV_MEGA_HINT bit 5): hop buffers used round-robin over the virtual layers (24 layers + the
+// tail per step), so that a buffer comes up again only n layers later, when no L2 or L1 still holds its lines, and the payload
+// can be read with plain loads that ALLOCATE in L2 -- the 4 members of a group that share an XCD then fetch a line from the
+// memory side once instead of four times (the all-gather is 18 MB per layer of memory-side reads, as much as the K/V).  A stale
+// line that survived anyway fails the tag check (epochs never repeat, not even across launches: ep_base) and the reader falls
+// back to the sc1 sweep.  MEASURED on MI355X: 16 buffer sets alone cost 4 % (586-591 vs 566 us per step: the one 0.9 MB set
+// stays resident on the memory side, 14 MB of rotating lines do not), and the L2-shared payload read gains nothing on top.
+// Default: one set, sc1 payload reads.
+__device__ __forceinline__ gu64* hop_slot(const Ctx& c, int s, int l) {
+  return c.hop_base + (size_t)((unsigned)(s * c.nlayer + l) % (unsigned)c.ring) * ((size_t)MG_GROUPS * HOP_GROUP);
 }
 
 __device__ __forceinline__ bool group_done(const Ctx& c) {
@@ -505,10 +543,11 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
 #pragma unroll
   for (int k = 0; k < 8; ++k) gC[k] = bC[k] = gA[k] = bA[k] = 0.f;
   for (int s = 0; s < a.nsteps; ++s) {
-    const unsigned ep0 = (unsigned)s * (unsigned)EPS;  // epoch of hop i of this step = ep0 + i + 1
+    const unsigned ep0 = a.ep_base + (unsigned)s * (unsigned)EPS;  // epoch of hop i of this step = ep0 + i + 1
     for (int l = 0; l < a.L; ++l) {
       const float* lp = a.fpack + (size_t)l * FP_LAYER;
       relaunder(q);
+      q.hop = hop_slot(q, s, l);
       q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer;
       MG_STAMP(q, 0);
       const int ra = q.cw;                             // this wave's row
@@ -608,6 +647,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
     }
     relaunder(q);
     // ---- tail: hop A' -> LayerNorm2 of the last layer -> XS; then the samplers
+    q.hop = hop_slot(q, s, a.L);
     const unsigned epA = ep0 + 4 * a.L + 1, epE = ep0 + 4 * a.L + 2;
     if (sweeper && q.cw < R) {
       const int ra = q.cw;
@@ -671,9 +711,10 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         }
       }
       if (ok && s + 1 < a.nsteps) {
+        gu64* hn = hop_slot(q, s + 1, 0);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) gstore(q.hop + HOP_A + r * 512 + k * 64 + q.lane, epN, __float_as_uint(x0[k]));
-        if (q.lane == 0) gstore(q.hop + HOP_ST + r, epN, (unsigned)now_active);
+        for (int k = 0; k < 8; ++k) gstore(hn + HOP_A + r * 512 + k * 64 + q.lane, epN, __float_as_uint(x0[k]));
+        if (q.lane == 0) gstore(hn + HOP_ST + r, epN, (unsigned)now_active);
       }
     }
   }
@@ -705,10 +746,11 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
   wload(wA1, p1_src(0) + (size_t)(WI_P1 / 2) * 64);
 
   for (int s = 0; s < a.nsteps; ++s) {
-    const unsigned ep0 = (unsigned)s * (unsigned)EPS;
+    const unsigned ep0 = a.ep_base + (unsigned)s * (unsigned)EPS;
     for (int l = 0; l < a.L; ++l) {
       const float* lp = a.fpack + (size_t)l * FP_LAYER;
       relaunder(q);
+      q.hop = hop_slot(q, s, l);
       q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer;
       MG_STAMP(q, 0);
       // ================= P1: q,k,v of head `head` for the own rows, K/V append, attention
@@ -905,7 +947,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         }
         const unsigned ep = l + 1 < a.L ? ep0 + 4 * (l + 1) + 1 : ep0 + 4 * a.L + 1;
         if (q.lane < R * 16)
-          gstore(q.hop + HOP_A + (q.lane >> 4) * 512 + 16 * q.member + (q.lane & 15), ep,
+          gstore(hop_slot(q, s, l + 1) + HOP_A + (q.lane >> 4) * 512 + 16 * q.member + (q.lane & 15), ep,
                  __float_as_uint(((const float*)(smem + L_STAGE))[q.lane]));
       }
       MG_STAMP(q, 23);
@@ -913,6 +955,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
     // ================= tail: logits split over the members (tiles member, member + 32, and tile 64 on member 0)
     const unsigned epE = ep0 + 4 * a.L + 2;
     relaunder(q);
+    q.hop = hop_slot(q, s, a.L);
     MG_BAR();                                                            // B1: XS holds LN2(y) of the last layer
     if (*st_abort(q)) return;
     gemm_chunk<3>(q, wA0, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 3);
@@ -945,7 +988,11 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   c.head = c.member >> 1; c.half = c.member & 1;
   c.R = a.B > c.group ? (a.B - c.group + MG_GROUPS - 1) / MG_GROUPS : 0;
   if (c.R == 0) return;
-  c.hop = (gu64*)a.hop + (size_t)c.group * HOP_GROUP;
+  c.hop_base = (gu64*)a.hop + (size_t)c.group * HOP_GROUP;
+  c.hop = c.hop_base;
+  c.ring = a.ring > 0 ? a.ring : 1;
+  c.nlayer = a.L + 1;
+  c.bulk_plain = c.ring > 1 && ((a.hint_mask >> 5) & 1);
   c.err = (gu32*)a.err;
   c.prof = a.prof ? a.prof + ((size_t)blockIdx.x * 8 + c.wave) * 32 : nullptr;
   c.prof_on = false;
@@ -1003,7 +1050,7 @@ __global__ __launch_bounds__(MG_THREADS, 1) void mega_census_kernel(unsigned* ws
 bool mega_shape_ok(int dim, int n_head, int ffn, int vocab) { return dim == D && n_head == NH && ffn == FF && vocab >= 64 && vocab <= VPAD; }
 size_t mega_layer_pack_halfs() { return LAYER_HALFS; }
 size_t mega_logits_pack_halfs() { return LOGIT_HALFS; }
-size_t mega_hop_bytes() { return (size_t)MG_GROUPS * HOP_GROUP * 8; }
+size_t mega_hop_bytes(int ring) { return (size_t)(ring > 0 ? ring : 1) * MG_GROUPS * HOP_GROUP * 8; }
 
 // fragment of one KiB-instruction: lane ln holds W[row0 + (ln & 15)][k0 + 8 (ln >> 4) .. +8]
 static void pack_frag(const float* w, int ldw, int row0, int nrows, int k0, _Float16* dst) {
