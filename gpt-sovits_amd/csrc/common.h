@@ -138,6 +138,21 @@ int launch_gemm_sk(int dtype, const ConvArgs& a, hipStream_t s);
 // LDS-staged variant for stride-1 convs (conv_lds.hip): 0 = launched, 1 = not eligible, <0 = error
 int launch_conv_lds(int dtype, const ConvArgs& a, hipStream_t s);
 
+// fused ResBlock pair of the generator's narrow stages (conv_pair.hip): y = (convs2(lrelu(convs1(lrelu(x)))) + x) * scale [+ y]
+struct ConvPairArgs {
+  const _Float16* x = nullptr;     // [T][ldx] fp16, channels-last
+  const _Float16* w1 = nullptr;    // [C][taps * C] tap-major, dilation `dil`
+  const float* b1 = nullptr;
+  const _Float16* w2 = nullptr;    // [C][taps * C], dilation 1
+  const float* b2 = nullptr;
+  _Float16* y = nullptr;           // [T][ldy]
+  int T = 0, C = 0, taps = 0, dil = 1, ldx = 0, ldy = 0;
+  float scale = 1.f;
+  int accumulate = 0;
+};
+bool conv_pair_eligible(int dtype, int C, int taps, int dil, int T);
+int launch_conv_pair(const ConvPairArgs& a, hipStream_t s);
+
 // fused attention, fp16, head dim 64 (attn.hip); vt_buf: heads * 64 * ceil32(T) halfs of scratch
 // rope_cs != null: rotate the first 2*rope_half channels of q and k in place first (cos|sin table [T][rope_half][2])
 int launch_flash_attn64_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* vt_buf, int T, int heads,

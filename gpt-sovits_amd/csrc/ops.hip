@@ -300,6 +300,15 @@ int gsv_op_magnitude(const float* re_im, int T, int bins, float eps, int frame_l
   return GSV_OK;
 }
 
+int gsv_op_conv_pair(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int T, int C, int taps,
+                     int dil, float scale, int accumulate, gsv_stream_t stream) {
+  GSV_REQUIRE(gsv::conv_pair_eligible(GSV_F16, C, taps, dil, T), "op_conv_pair: C must be 16 or 32, taps odd <= 11, (taps - 1) / 2 * dil <= 25, T >= 256");
+  gsv::ConvPairArgs a;
+  a.x = (const _Float16*)x; a.w1 = (const _Float16*)w1; a.b1 = b1; a.w2 = (const _Float16*)w2; a.b2 = b2; a.y = (_Float16*)y;
+  a.T = T; a.C = C; a.taps = taps; a.dil = dil; a.ldx = C; a.ldy = C; a.scale = scale; a.accumulate = accumulate;
+  return gsv::launch_conv_pair(a, (hipStream_t)stream);
+}
+
 int gsv_op_aff_mix(const float* x, const float* y, const float* t, long long n, float* out, gsv_stream_t stream) {
   GSV_REQUIRE(x && y && t && out && n > 0, "op_aff_mix: bad argument");
   hipLaunchKernelGGL(gsv::aff_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, t, n, out);

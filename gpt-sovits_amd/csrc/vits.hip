@@ -1011,6 +1011,19 @@ int gsv_vits_decode(gsv_vits_t* h, const int32_t* codes, int T, const int32_t* p
       for (int k = 0; k < 3; ++k) {
         const Conv& c1 = h->rb1[(i * c.n_resblocks + j) * 3 + k];
         const Conv& c2 = h->rb2[(i * c.n_resblocks + j) * 3 + k];
+        if (c1.b && c2.b && c1.taps == c2.taps && conv_pair_eligible(h->dtype, ch, c1.taps, c.rb_dilations[j][k], Tout)) {
+          // narrow stages: the pair in one kernel, the intermediate tensor never leaves the CU (conv_pair.hip)
+          ConvPairArgs pa;
+          pa.x = (const _Float16*)xr; pa.w1 = (const _Float16*)c1.w; pa.b1 = c1.b; pa.w2 = (const _Float16*)c2.w; pa.b2 = c2.b;
+          pa.T = Tout; pa.C = ch; pa.taps = c1.taps; pa.dil = c.rb_dilations[j][k]; pa.ldx = ch; pa.ldy = ch;
+          if (k < 2) { pa.y = (_Float16*)R; }
+          else { pa.y = (_Float16*)xs; pa.scale = 1.f / (float)c.n_resblocks; pa.accumulate = j > 0; }
+          // the pair reads x as window AND residual: it must not be overwritten in place
+          if ((const void*)pa.y == xr) { pa.y = (_Float16*)xt; }
+          GSV_RC(launch_conv_pair(pa, s));
+          if (k < 2) { if (pa.y == (_Float16*)xt) { std::swap(xt, R); } xr = R; }
+          continue;
+        }
         ConvOpt o1; o1.pre_act = ACT_LRELU; o1.pre_slope = 0.1f; o1.dil = c.rb_dilations[j][k];
         GSV_RC(conv(h, s, c1, xr, ch, Tout, xt, Tout, o1));
         ConvOpt o2; o2.pre_act = ACT_LRELU; o2.pre_slope = 0.1f; o2.res = xr; o2.ldr = ch;
@@ -1371,6 +1384,17 @@ int gsv_vocoder_forward(gsv_vocoder_t* v, const float* mel, int F, float* wav, g
       for (int k = 0; k < 3; ++k) {
         const Conv& c1 = v->rb1[(i * c.n_resblocks + j) * 3 + k];
         const Conv& c2 = v->rb2[(i * c.n_resblocks + j) * 3 + k];
+        if (!big && c1.b && c2.b && c1.taps == c2.taps && conv_pair_eligible(h->dtype, ch, c1.taps, c.rb_dilations[j][k], Tout)) {
+          ConvPairArgs pa;                                // narrow stages of the v4 HiFi-GAN vocoder: same fused pair as gsv_vits_decode
+          pa.x = (const _Float16*)xr; pa.w1 = (const _Float16*)c1.w; pa.b1 = c1.b; pa.w2 = (const _Float16*)c2.w; pa.b2 = c2.b;
+          pa.T = Tout; pa.C = ch; pa.taps = c1.taps; pa.dil = c.rb_dilations[j][k]; pa.ldx = ch; pa.ldy = ch;
+          if (k < 2) { pa.y = (_Float16*)R; }
+          else { pa.y = (_Float16*)xs; pa.scale = 1.f / (float)c.n_resblocks; pa.accumulate = j > 0; }
+          if ((const void*)pa.y == xr) { pa.y = (_Float16*)xt; }
+          GSV_RC(launch_conv_pair(pa, s));
+          if (k < 2) { if (pa.y == (_Float16*)xt) { std::swap(xt, R); } xr = R; }
+          continue;
+        }
         ConvOpt o1; o1.dil = c.rb_dilations[j][k];
         ConvOpt o2; o2.res = xr; o2.ldr = ch;
         const void* in1 = xr;

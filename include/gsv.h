@@ -288,6 +288,11 @@ int gsv_op_layernorm(const void* x, const void* res, const float* gamma, const f
  *  gsv_op_time_mean: x [dev] fp32 [T][ld] -> out[ld] = mean over T (ERes2NetV2.forward3, eres2net/ERes2NetV2.py:258) */
 int gsv_op_frame(const float* x, int n, int frame_len, int hop, int pad, int ld, int T_out, void* out, int dtype, gsv_stream_t stream);
 int gsv_op_magnitude(const float* re_im, int T, int bins, float eps, int frame_ld, float* spec, gsv_stream_t stream);
+/* one HiFi-GAN ResBlock pair of the generator's narrow stages in one kernel (fp16, C = 16 or 32, reference module/models.py:262-283):
+ * y = (convs2(lrelu(convs1(lrelu(x)))) + x) * scale [+ y]; x, y [dev] f16 [T][C] (y must not alias x); w1 / w2 [dev] f16 [C][taps*C]
+ * tap-major, convs1 dilated by `dil`, convs2 dilation 1; b1 / b2 [dev] fp32 [C].  Same rounding points as two gsv_op_conv1d launches. */
+int gsv_op_conv_pair(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int T, int C, int taps,
+                     int dil, float scale, int accumulate, gsv_stream_t stream);
 int gsv_op_aff_mix(const float* x, const float* y, const float* t, long long n, float* out, gsv_stream_t stream);
 int gsv_op_time_mean(const float* x, int T, int ld, float* out, gsv_stream_t stream);
 int gsv_op_channel_norm(const void* x, int T, int C, const float* gamma, const float* beta, float eps, int act, float* scratch,
