@@ -6,6 +6,7 @@
 // 2 M / 4.1 M samples: 131 MB per tensor).  As two launches a pair moves 5 tensors through HBM (x in, t out | t in, x as
 // residual, y out); fused it moves 2 (x once -- the residual rows come out of L2, where the window load left them -- and y).
 // Construction = conv_narrow_f16_kernel (conv_lds.hip) twice inside one persistent 256-step tile:
+//   convs1's weights in registers (A-fragments, loaded once per wave), convs2's in LDS
 //   window  x[t0 - h2 - h1, t0 - h2 + 288 + h1) -> LDS (lrelu while staging), prefetched one tile ahead in registers
 //   convs1 over 288 rows (9 MFMA column tiles dealt to the 4 waves) -> + bias -> fp16 -> lrelu -> zero outside [0, T)  -> LDS
 //   convs2 over the tile's 256 rows from that LDS image -> fp32 tile transposed through LDS -> + bias + x, * scale, (+ y) -> rows
@@ -33,8 +34,9 @@ __device__ __forceinline__ T4 lrelu4(T4 v, float s) { T4 t = v * (_Float16)s; re
 constexpr int ROWS_Y = 288;      // intermediate rows per tile (9 x 32 >= 256 + 2 * 5)
 constexpr int ROWS_X = 338;      // window rows at most (288 + 2 * 5 * 5)
 
-template <int CC, bool ACCU>
-__global__ __launch_bounds__(256) void conv_pair_f16_kernel(ConvPairArgs a, int ntiles) {
+// second launch bound = waves per SIMD the register allocation must leave room for: 2 workgroups per CU at C = 32, 3 at C = 16
+template <int CC, int TAPS, bool ACCU>
+__global__ __launch_bounds__(256, CC == 32 ? 2 : 3) void conv_pair_f16_kernel(ConvPairArgs a, int ntiles) {
   constexpr int G = 8, KC = 16, CT = 32, WN = 4, TN = 2, NT = 256;
   constexpr int LDX = CC + G, VPR = CC / G;
   constexpr int XB = (ROWS_X * VPR + NT - 1) / NT;
@@ -42,14 +44,13 @@ __global__ __launch_bounds__(256) void conv_pair_f16_kernel(ConvPairArgs a, int 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = (T*)smem;                                   // [ROWS_X][LDX]; the epilogue's fp32 [PR][LDO] tile aliases it
   T* ys = xs + (size_t)ROWS_X * LDX;                  // [ROWS_Y][LDX] lrelu(convs1(...)) of this tile
-  T* w1s = ys + (size_t)ROWS_Y * LDX;                 // [taps][CT][LDX]
-  T* w2s = w1s + (size_t)a.taps * CT * LDX;
+  T* w2s = ys + (size_t)ROWS_Y * LDX;                 // [TAPS][CT][LDX] convs2's weights; convs1's live in registers (below)
   float* os = (float*)smem;
   static_assert(PR * LDO * 4 <= ROWS_X * LDX * 2, "epilogue tile must fit in the window");
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const T* __restrict__ x = a.x;
-  const int h2 = (a.taps - 1) / 2, h1 = h2 * a.dil;
+  const int h2 = (TAPS - 1) / 2, h1 = h2 * a.dil;
   const int rows_win = ROWS_Y + 2 * h1;
   const int total = rows_win * VPR;
   const int ecg = tid % IPR, ec = 4 * ecg;
@@ -62,19 +63,28 @@ __global__ __launch_bounds__(256) void conv_pair_f16_kernel(ConvPairArgs a, int 
   for (int g = 0; g < 4; ++g)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int c = 8 * g + 4 * h + j; b1v[g][j] = c < CC ? a.b1[c] : 0.f; }
-  // ---- both convs' weights, once per workgroup
+  // ---- convs2's weights into LDS, convs1's into registers (every wave multiplies all of them by its own column tiles: TAPS *
+  // CC / 16 A-fragments = 44 / 88 VGPRs at 11 taps; keeping them out of LDS is what lets 2 (C = 32) to 4 (C = 16) workgroups
+  // share a CU -- with both slabs in LDS the C = 32 kernel ran one workgroup per CU and was slower than two launches)
   {
-    const int totw = a.taps * CT * VPR;
-    for (int v = tid; v < 2 * totw; v += NT) {
-      const int which = v >= totw, u = v - which * totw;
-      const int tap = u / (CT * VPR), rem = u - tap * (CT * VPR);
+    const int totw = TAPS * CT * VPR;
+    for (int v = tid; v < totw; v += NT) {
+      const int tap = v / (CT * VPR), rem = v - tap * (CT * VPR);
       const int row = rem / VPR, col = rem - row * VPR;
-      const T* w = which ? a.w2 : a.w1;
       F val = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (row < CC) val = *(const F*)(w + (long long)row * a.taps * CC + (long long)tap * CC + col * G);
-      *(F*)((which ? w2s : w1s) + ((size_t)tap * CT + row) * LDX + col * G) = val;
+      if (row < CC) val = *(const F*)(a.w2 + (long long)row * TAPS * CC + (long long)tap * CC + col * G);
+      *(F*)(w2s + ((size_t)tap * CT + row) * LDX + col * G) = val;
     }
   }
+  F w1r[TAPS * (CC / KC)];
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < CC / KC; ++ks) {
+      F val = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (r < CC) val = *(const F*)(a.w1 + (long long)r * TAPS * CC + (long long)tap * CC + ks * KC + G * h);
+      w1r[tap * (CC / KC) + ks] = val;
+    }
   auto load_window = [&](int tile, F* regs) {
     const int win_start = tile * 256 - h2 - h1;
 #pragma unroll
@@ -122,15 +132,14 @@ __global__ __launch_bounds__(256) void conv_pair_f16_kernel(ConvPairArgs a, int 
       f16v acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-      for (int tap = 0; tap < a.taps; ++tap) {
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
         const int shift = tap * a.dil;
-        const T* wb = w1s + (size_t)tap * CT * LDX;
 #pragma unroll
         for (int ks = 0; ks < CC / KC; ++ks) {
           const int kk = ks * KC + G * h;
-          const F af = *(const F*)(wb + (size_t)r * LDX + kk);
           const F bf = *(const F*)(xs + (size_t)(n1 * 32 + r + shift) * LDX + kk);
-          mma32p(acc, af, bf);
+          mma32p(acc, w1r[tap * (CC / KC) + ks], bf);
         }
       }
       const int row = n1 * 32 + r, t = t0 - h2 + row;
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_pair_f16_kernel(ConvPairArgs a, int 
     for (int n = 0; n < TN; ++n)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc2[n][i] = 0.f;
-    for (int tap = 0; tap < a.taps; ++tap) {
+    for (int tap = 0; tap < TAPS; ++tap) {
       const T* wb = w2s + (size_t)tap * CT * LDX;
 #pragma unroll
       for (int ks = 0; ks < CC / KC; ++ks) {
@@ -207,16 +216,16 @@ __global__ __launch_bounds__(256) void conv_pair_f16_kernel(ConvPairArgs a, int 
   }
 }
 
-template <int CC>
+template <int CC, int TAPS>
 int launch_pair(const ConvPairArgs& a, hipStream_t s) {
   const int ntiles = cdiv(a.T, 256);
-  const size_t lds = ((size_t)ROWS_X + ROWS_Y + 2 * (size_t)a.taps * 32) * (CC + 8) * 2;
+  const size_t lds = ((size_t)ROWS_X + ROWS_Y + (size_t)TAPS * 32) * (CC + 8) * 2;
   static const int cap = getenv("GSV_PAIR_PER_CU") ? std::max(1, atoi(getenv("GSV_PAIR_PER_CU"))) : 3;
   const int per_cu = std::max(1, std::min(cap, (int)((156 * 1024) / lds)));
   const int grid = std::min(ntiles, 256 * per_cu);
 #define GSV_PAIR(A)                                                                                                        \
   do {                                                                                                                     \
-    auto kern = conv_pair_f16_kernel<CC, A>;                                                                               \
+    auto kern = conv_pair_f16_kernel<CC, TAPS, A>;                                                                         \
     static bool set = false;                                                                                               \
     if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, ntiles);                                                    \
@@ -226,6 +235,17 @@ int launch_pair(const ConvPairArgs& a, hipStream_t s) {
 #undef GSV_PAIR
   GSV_HIP(hipGetLastError());
   return GSV_OK;
+}
+
+template <int CC>
+int launch_pair_taps(const ConvPairArgs& a, hipStream_t s) {
+  switch (a.taps) {
+    case 3: return launch_pair<CC, 3>(a, s);
+    case 5: return launch_pair<CC, 5>(a, s);
+    case 7: return launch_pair<CC, 7>(a, s);
+    case 9: return launch_pair<CC, 9>(a, s);
+    default: return launch_pair<CC, 11>(a, s);
+  }
 }
 
 }  // namespace
@@ -242,7 +262,7 @@ int launch_conv_pair(const ConvPairArgs& a, hipStream_t s) {
               a.C, a.taps, a.dil, a.T);
   GSV_REQUIRE(a.ldx % 8 == 0 && a.ldy % 4 == 0 && ((uintptr_t)a.x % 16) == 0 && ((uintptr_t)a.w1 % 16) == 0 && ((uintptr_t)a.w2 % 16) == 0,
               "conv_pair: operands must be 16-byte aligned");
-  return a.C == 16 ? launch_pair<16>(a, s) : launch_pair<32>(a, s);
+  return a.C == 16 ? launch_pair_taps<16>(a, s) : launch_pair_taps<32>(a, s);
 }
 
 }  // namespace gsv
