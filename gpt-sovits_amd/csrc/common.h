@@ -137,6 +137,8 @@ int launch_conv_gemm(int dtype, const ConvArgs& a, hipStream_t s);
 int launch_gemm_sk(int dtype, const ConvArgs& a, hipStream_t s);
 // LDS-staged variant for stride-1 convs (conv_lds.hip): 0 = launched, 1 = not eligible, <0 = error
 int launch_conv_lds(int dtype, const ConvArgs& a, hipStream_t s);
+// persistent 128-channel tile convolution (conv_wide.hip): 1 = not eligible, 0 = launched, < 0 error
+int launch_conv_wide(int dtype, const ConvArgs& a, hipStream_t s);
 
 // fused ResBlock pair of the generator's narrow stages (conv_pair.hip): y = (convs2(lrelu(convs1(lrelu(x)))) + x) * scale [+ y]
 struct ConvPairArgs {

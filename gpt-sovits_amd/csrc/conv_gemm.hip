@@ -219,7 +219,9 @@ int launch_conv_gemm(int dtype, const ConvArgs& a_in, hipStream_t s) {
     if (rc <= 0) return rc;
   }
   if (!no_lds) {
-    const int rc = launch_conv_lds(dtype, a, s);
+    int rc = launch_conv_wide(dtype, a, s);
+    if (rc <= 0) return rc;
+    rc = launch_conv_lds(dtype, a, s);
     if (rc <= 0) return rc;
   }
   if (dtype == GSV_F16) return launch_t<_Float16>(a, s);

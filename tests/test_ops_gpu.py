@@ -423,3 +423,30 @@ def test_conv_pair_matches_two_launches(C_, k, dil, T, accum):
     with pytest.raises(RuntimeError):
         _lib.check(_lib.lib().gsv_op_conv_pair(xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), yd.data_ptr(),
                                                T, 48, k, dil, scale, 0, None), "gsv_op_conv_pair")
+
+
+@pytest.mark.parametrize("k,dil,mode", [(3, 1, "plain"), (7, 3, "res"), (11, 5, "res"), (11, 1, "res_acc"), (7, 5, "acc")])
+def test_wide_persistent_conv_matches_tile_kernel(k, dil, mode):
+    """conv_wide_f16_kernel (persistent, C = 128, T >= 16384) vs conv_lds_kernel (one tile per workgroup) on the same data:
+    the tile kernel is reached by convolving overlapping pieces shorter than 16384 steps, whose interior rows must be
+    BIT-IDENTICAL to the persistent kernel's; and vs torch fp32 within fp16 tolerance.  T = 20000 is ragged (last tile 32 rows)."""
+    torch.manual_seed(k * 7 + dil)
+    C_, T = 128, 20000
+    x = torch.randn(C_, T).half().float()
+    w = (torch.randn(C_, C_, k) / (C_ * k) ** 0.5).half().float()
+    b = torch.randn(C_) * 0.1
+    res = torch.randn(C_, T).half().float() if "res" in mode else None
+    y0 = torch.randn(C_, T).half().float() if "acc" in mode else None
+    scale = 1.0 / 3.0 if "acc" in mode else 1.0
+    full = _conv(x, w, b, torch.float16, dil=dil, pre_lrelu=0.1, res=res, scale=scale, accumulate=y0)
+    halo = (k - 1) // 2 * dil
+    for lo, hi in ((0, 12000), (8000, 20000)):
+        piece = _conv(x[:, lo:hi], w, b, torch.float16, dil=dil, pre_lrelu=0.1, res=res[:, lo:hi] if res is not None else None,
+                      scale=scale, accumulate=y0[:, lo:hi] if y0 is not None else None)
+        a, z = (0 if lo == 0 else halo), (hi - lo if hi == T else hi - lo - halo)     # rows whose receptive field lies inside the piece
+        assert torch.equal(piece[:, a:z], full[:, lo + a:lo + z]), f"max diff {(piece[:, a:z] - full[:, lo + a:lo + z]).abs().max()}"
+    ref = F.conv1d(F.leaky_relu(x, 0.1).unsqueeze(0), w, b, dilation=dil, padding=halo)[0]
+    if res is not None:
+        ref = ref + res
+    ref = ref * scale + (y0 if y0 is not None else 0)
+    assert (full - ref).abs().max() <= 2e-2

@@ -15,6 +15,8 @@ _lib.init(0)
 SHAPES = [(16, 16, 3, 1, 4096000), (16, 16, 11, 5, 4096000), (32, 32, 7, 3, 2048000), (64, 64, 11, 5, 1024000),
           (128, 128, 7, 3, 512000), (256, 256, 11, 5, 64000), (256, 256, 3, 1, 64000)]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+if len(sys.argv) > 2:            # explicit shapes: CinxCoutxkxdilxT ...
+    SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[2:]]
 for (Cin, Cout, k, dil, T) in SHAPES:
     x = torch.randn(T, Cin, device=DEV, dtype=torch.float16)
     w = (torch.randn(Cout, k * Cin, device=DEV) / (Cin * k) ** 0.5).half()
