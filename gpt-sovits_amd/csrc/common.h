@@ -73,6 +73,12 @@ __device__ __forceinline__ int xcd_virtual_id(int orig, int nwg) {
 static inline size_t dt_size(int dt) { return dt == GSV_F16 ? 2 : 4; }
 
 // ------------------------------------------------------------------------------------
+// Workgroup barrier for LDS producer / consumer hand-offs.  __syncthreads() also emits `s_waitcnt vmcnt(0)`: it waits for every
+// outstanding GLOBAL load and store of the wave -- in the persistent conv kernels that is the next tile's window prefetch and
+// the previous tile's output stores, i.e. exactly the HBM time the persistence was meant to hide (same lesson as t2s_mega.hip).
+// Only LDS traffic has to be complete here; results of global loads are waited for where they are used.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // generic channels-last implicit-GEMM conv (conv_gemm.hip)
 // ------------------------------------------------------------------------------------
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3, ACT_MISH = 4, ACT_CLAMP1 = 5, ACT_SILU = 6, ACT_GELU = 7,
@@ -127,6 +133,7 @@ struct ConvArgs {
   int ups_u = 0, ups_pad = 0, ups_cout = 0;  // transposed-conv scatter: row = s*u + n/ups_cout - pad
   int Z = 1;
   long long xz = 0, wz = 0, yz = 0, rz = 0;  // batch strides in elements
+  unsigned long long* prof = nullptr;   // conv_wide.hip measurement runs (GSV_WIDE_PROF): s_memrealtime stamps of one tile
   int bz = 0;                                // batch stride of bias / gate (grouped convs)
   int xcd_order = 0;                         // set by the launcher: 1 = decode tile ids through xcd_virtual_id
   int w_nt = 0;                              // weights are loaded non-temporal (streamed once per step: keep them out of the

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(ConvArgs a) {
   }
 
   // ---- epilogue: lane holds column t (time), rows (i&3)+8(i>>2)+4h (output channels)
+  const bool has_act = a.post_act != ACT_NONE;        // one uniform test per value instead of post_act_f's chain of five
   const bool vec_ok = ((a.ldy & 3) == 0) && ((a.y_col0 & 3) == 0) && ((a.ldr & 3) == 0) &&
                       (a.ups_u == 0 || (a.ups_cout & 3) == 0);
 #pragma unroll
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(ConvArgs a) {
           if (a.gate) u *= a.gate[z * a.bz + oc + j];
           if (a.res) u += a.res_f32 ? ((const float*)a.res)[roff + j] : to_f(((const T*)a.res)[roff + j]);
           u *= a.scale;
-          u = post_act_f(a.post_act, u);
+          if (has_act) u = post_act_f(a.post_act, u);
           if (a.accumulate) u += a.out_f32 ? ((float*)a.y)[yoff + j] : to_f(((T*)a.y)[yoff + j]);
           v[j] = u;
         }

@@ -16,6 +16,8 @@
 
 #include <algorithm>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace gsv {
@@ -283,37 +285,42 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
         else for (int j = 0; j < env; ++j) ya[e][j] = yp[j];
       }
     }
-#pragma unroll
-    for (int e = 0; e < NI; ++e) {
-      const int q = pass * NI + e;
-      const int tl = (tid + e * NT) / IPR;
-      const int t = t0 + pass * PR + tl;
-      const int orow = a.ups_u > 0 ? t * a.ups_u + epp - a.ups_pad : t;
-      if (!(t < a.T_virt && env > 0 && orow >= 0 && orow < a.T_out)) continue;
-      const f4 av = *(const f4*)(os + (size_t)tl * LDO + 4 * ecg);
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float u = av[j] + ebias[j];
-        if (RES) u += to_f(rv[RES_LAZY ? e : q][j]);
-        u *= a.scale;
-        u = post_act_f(a.post_act, u);
-        if (PRE_ACC) u += to_f(yv[q][j]);
-        else if (ACCU) u += to_f(ya[e][j]);
-        v[j] = u;
+    // the activation code is tested once per pass, not per element (conv_wide.hip: ~50 scalar instructions per value otherwise)
+    auto items = [&](auto act_tag) {
+  #pragma unroll
+      for (int e = 0; e < NI; ++e) {
+        const int q = pass * NI + e;
+        const int tl = (tid + e * NT) / IPR;
+        const int t = t0 + pass * PR + tl;
+        const int orow = a.ups_u > 0 ? t * a.ups_u + epp - a.ups_pad : t;
+        if (!(t < a.T_virt && env > 0 && orow >= 0 && orow < a.T_out)) continue;
+        const f4 av = *(const f4*)(os + (size_t)tl * LDO + 4 * ecg);
+        float v[4];
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float u = av[j] + ebias[j];
+          if (RES) u += to_f(rv[RES_LAZY ? e : q][j]);
+          u *= a.scale;
+          if (decltype(act_tag)::value) u = post_act_f(a.post_act, u);
+          if (PRE_ACC) u += to_f(yv[q][j]);
+          else if (ACCU) u += to_f(ya[e][j]);
+          v[j] = u;
+        }
+        const long long yoff = (long long)orow * a.ldy + a.y_col0 + eoc;
+        const bool vec = vec_ok && env == 4;
+        if (a.out_f32) {
+          float* yp = (float*)a.y + yoff;
+          if (vec) *(f4*)yp = (f4){v[0], v[1], v[2], v[3]};
+          else for (int j = 0; j < env; ++j) yp[j] = v[j];
+        } else {
+          T* yp = (T*)a.y + yoff;
+          if (vec) *(T4*)yp = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+          else for (int j = 0; j < env; ++j) yp[j] = (T)v[j];
+        }
       }
-      const long long yoff = (long long)orow * a.ldy + a.y_col0 + eoc;
-      const bool vec = vec_ok && env == 4;
-      if (a.out_f32) {
-        float* yp = (float*)a.y + yoff;
-        if (vec) *(f4*)yp = (f4){v[0], v[1], v[2], v[3]};
-        else for (int j = 0; j < env; ++j) yp[j] = v[j];
-      } else {
-        T* yp = (T*)a.y + yoff;
-        if (vec) *(T4*)yp = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-        else for (int j = 0; j < env; ++j) yp[j] = (T)v[j];
-      }
-    }
+    };
+    if (a.post_act == ACT_NONE) items(std::false_type{});
+    else items(std::true_type{});
     if (RES_LAZY && pass + 1 < WN) load_res_pass(pass + 1);
   }
 }
@@ -462,34 +469,39 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < NI; ++e) {
-      const int q = pass * NI + e;
-      const int tl = (tid + e * NT) / IPR;
-      const int t = t0 + pass * PR + tl;
-      if (!(t < a.T_virt && env > 0)) continue;
-      const f4 av = *(const f4*)(os + (size_t)tl * LDO + 4 * ecg);
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float u = (av[j] + ebias[j]) * egate[j];
-        if (RES) u += to_f(rv[q][j]);
-        u *= a.scale;
-        u = post_act_f(a.post_act, u);
-        v[j] = u;
+    // the activation code is tested once per pass, not per element (conv_wide.hip: ~50 scalar instructions per value otherwise)
+    auto items = [&](auto act_tag) {
+  #pragma unroll
+      for (int e = 0; e < NI; ++e) {
+        const int q = pass * NI + e;
+        const int tl = (tid + e * NT) / IPR;
+        const int t = t0 + pass * PR + tl;
+        if (!(t < a.T_virt && env > 0)) continue;
+        const f4 av = *(const f4*)(os + (size_t)tl * LDO + 4 * ecg);
+        float v[4];
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float u = (av[j] + ebias[j]) * egate[j];
+          if (RES) u += to_f(rv[q][j]);
+          u *= a.scale;
+          if (decltype(act_tag)::value) u = post_act_f(a.post_act, u);
+          v[j] = u;
+        }
+        const long long yoff = ybase + (long long)t * a.ldy + a.y_col0 + ec;
+        const bool vec = vec_ok && env == 4 && ((ybase & 3) == 0);
+        if (a.out_f32) {
+          float* yp = (float*)a.y + yoff;
+          if (vec) *(f4*)yp = (f4){v[0], v[1], v[2], v[3]};
+          else for (int j = 0; j < env; ++j) yp[j] = v[j];
+        } else {
+          T* yp = (T*)a.y + yoff;
+          if (vec) *(T4*)yp = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+          else for (int j = 0; j < env; ++j) yp[j] = (T)v[j];
+        }
       }
-      const long long yoff = ybase + (long long)t * a.ldy + a.y_col0 + ec;
-      const bool vec = vec_ok && env == 4 && ((ybase & 3) == 0);
-      if (a.out_f32) {
-        float* yp = (float*)a.y + yoff;
-        if (vec) *(f4*)yp = (f4){v[0], v[1], v[2], v[3]};
-        else for (int j = 0; j < env; ++j) yp[j] = v[j];
-      } else {
-        T* yp = (T*)a.y + yoff;
-        if (vec) *(T4*)yp = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-        else for (int j = 0; j < env; ++j) yp[j] = (T)v[j];
-      }
-    }
+    };
+    if (a.post_act == ACT_NONE) items(std::false_type{});
+    else items(std::true_type{});
   }
 }
 
@@ -688,32 +700,36 @@ __global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, in
                   (f4){acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
       }
       __syncthreads();
-#pragma unroll
-      for (int e = 0; e < NI; ++e) {
-        const int q = pass * NI + e;
-        const int tl = (tid + e * NT) / IPR;
-        const int t = t0 + pass * PR + tl;
-        if (!(t < a.T_virt && t < a.T_out && env > 0)) continue;
-        const f4 av = *(const f4*)(os + (size_t)tl * LDO + 4 * ecg);
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float u = av[j] + ebias[j];
-          if (RES) u += (float)rv[q][j];
-          u *= a.scale;
-          u = post_act_f(a.post_act, u);
-          if (ACCU) u += (float)yv[q][j];
-          v[j] = u;
+      auto items = [&](auto act_tag) {      // activation code tested once per pass, not per element
+  #pragma unroll
+        for (int e = 0; e < NI; ++e) {
+          const int q = pass * NI + e;
+          const int tl = (tid + e * NT) / IPR;
+          const int t = t0 + pass * PR + tl;
+          if (!(t < a.T_virt && t < a.T_out && env > 0)) continue;
+          const f4 av = *(const f4*)(os + (size_t)tl * LDO + 4 * ecg);
+          float v[4];
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float u = av[j] + ebias[j];
+            if (RES) u += (float)rv[q][j];
+            u *= a.scale;
+            if (decltype(act_tag)::value) u = post_act_f(a.post_act, u);
+            if (ACCU) u += (float)yv[q][j];
+            v[j] = u;
+          }
+          if (a.out_f32) {                 // conv_post: one fp32 output channel
+            float* yp = (float*)a.y + (long long)t * a.ldy + a.y_col0 + ec;
+            for (int j = 0; j < env; ++j) yp[j] = v[j];
+          } else {
+            T* yp = (T*)a.y + (long long)t * a.ldy + a.y_col0 + ec;
+            if (vec_ok && env == 4) *(T4*)yp = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+            else for (int j = 0; j < env; ++j) yp[j] = (T)v[j];
+          }
         }
-        if (a.out_f32) {                 // conv_post: one fp32 output channel
-          float* yp = (float*)a.y + (long long)t * a.ldy + a.y_col0 + ec;
-          for (int j = 0; j < env; ++j) yp[j] = v[j];
-        } else {
-          T* yp = (T*)a.y + (long long)t * a.ldy + a.y_col0 + ec;
-          if (vec_ok && env == 4) *(T4*)yp = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-          else for (int j = 0; j < env; ++j) yp[j] = (T)v[j];
-        }
-      }
+      };
+      if (a.post_act == ACT_NONE) items(std::false_type{});
+      else items(std::true_type{});
     }
     __syncthreads();                 // the fp32 tile (aliasing the window) has been read by every thread
     store_window(nxt);

@@ -9,9 +9,11 @@
 // conv_narrow_f16_kernel): the NEXT tile's window is requested into registers before the current tile's tap loop and written to
 // LDS after its epilogue, and the residual rows of a pass are requested one pass ahead.  Arithmetic, MFMA order and epilogue formula are those of conv_lds_kernel<half, 2, 4, 2, 2, 128>:
 // results are bit-identical (tests/test_ops_gpu.py::test_wide_persistent_conv_matches_tile_kernel).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -98,9 +100,13 @@ __global__ __launch_bounds__(256) void conv_wide_f16_kernel(ConvArgs a, int rows
     store_window(first);
     store_w(0, w0);
   }
-  __syncthreads();
+  lds_barrier();
   for (; tile < ntiles; tile += gridDim.x) {
     const int t0 = tile * 256;
+    const bool pf = a.prof && blockIdx.x == 100 && tile == 100 + 3 * (int)gridDim.x && tid == 0;
+    int pi = 0;
+#define WSTAMP() do { if (pf) a.prof[pi++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    WSTAMP();
     // ---- requests that do not depend on this tile's arithmetic go out first
     F nxt[XB];
     load_window(min(tile + (int)gridDim.x, ntiles - 1), nxt);
@@ -142,13 +148,15 @@ __global__ __launch_bounds__(256) void conv_wide_f16_kernel(ConvArgs a, int rows
       }
       if (more) {
         store_w(buf ^ 1, wnx);
-        __syncthreads();
+        lds_barrier();
       }
+      WSTAMP();
     }
     // ---- epilogue through LDS (whole channels-last rows per store), one wave column per pass
 #pragma unroll
     for (int pass = 0; pass < WN; ++pass) {
-      __syncthreads();
+      lds_barrier();
+      WSTAMP();
       if (wn == pass) {
 #pragma unroll
         for (int m = 0; m < TM; ++m)
@@ -162,39 +170,50 @@ __global__ __launch_bounds__(256) void conv_wide_f16_kernel(ConvArgs a, int rows
             }
           }
       }
-      __syncthreads();
+      WSTAMP();
+      lds_barrier();
+      WSTAMP();
       T4 ya[ACCU ? NI : 1];
 #pragma unroll
       for (int e = 0; e < (ACCU ? NI : 0); ++e) {
         const int t = min(t0 + pass * PR + (tid + e * NT) / IPR, a.T_out - 1);
         ya[e] = *(const T4*)((const T*)a.y + (long long)t * a.ldy + ec);
       }
+      // The activation code is a run-time argument: tested per ELEMENT (as the tile kernel does) it cost ~50 scalar
+      // instructions and a branch per value -- 6.7 us of a 24 us tile, measured with in-kernel stamps.  Tested once per pass:
+      auto items = [&](auto act_tag) {
+        constexpr bool HAS_ACT = decltype(act_tag)::value;
 #pragma unroll
-      for (int e = 0; e < NI; ++e) {
-        const int tl = (tid + e * NT) / IPR;
-        const int t = t0 + pass * PR + tl;
-        if (t >= a.T_out) continue;
-        const f4 av = *(const f4*)(os + (size_t)tl * LDO + 4 * ecg);
-        float v[4];
+        for (int e = 0; e < NI; ++e) {
+          const int tl = (tid + e * NT) / IPR;
+          const int t = t0 + pass * PR + tl;
+          if (t >= a.T_out) continue;
+          const f4 av = *(const f4*)(os + (size_t)tl * LDO + 4 * ecg);
+          float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float u = av[j] + ebias[j];
-          if (RES) u += (float)rv[e][j];
-          u *= a.scale;
-          u = post_act_f(a.post_act, u);
-          if (ACCU) u += (float)ya[e][j];
-          v[j] = u;
+          for (int j = 0; j < 4; ++j) {
+            float u = av[j] + ebias[j];
+            if (RES) u += (float)rv[e][j];
+            u *= a.scale;
+            if (HAS_ACT) u = post_act_f(a.post_act, u);
+            if (ACCU) u += (float)ya[e][j];
+            v[j] = u;
+          }
+          *(T4*)((T*)a.y + (long long)t * a.ldy + ec) = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
         }
-        *(T4*)((T*)a.y + (long long)t * a.ldy + ec) = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-      }
+      };
+      if (a.post_act == ACT_NONE) items(std::false_type{});
+      else items(std::true_type{});
       if (RES && pass + 1 < WN) load_res_pass(pass + 1);
+      WSTAMP();
     }
     F w0[WLOADS];                    // tap 0's slab again (taps 2, 4, ... went through its buffer): an L2 hit, ~1 us per tile
     load_w(0, w0);
-    __syncthreads();                 // the fp32 tile (aliasing the window) has been read by every thread
+    lds_barrier();                 // the fp32 tile (aliasing the window) has been read by every thread
     store_window(nxt);
     store_w(0, w0);
-    __syncthreads();
+    lds_barrier();
+    WSTAMP();
   }
 }
 
@@ -213,13 +232,18 @@ int launch_conv_wide(int dtype, const ConvArgs& a, hipStream_t s) {
   const int ntiles = cdiv(a.T_virt, 256);
   const size_t lds = ((size_t)306 + 2 * 128) * 136 * 2;
   const int grid = std::min(ntiles, 256);
+  ConvArgs b = a;
+  static unsigned long long* d_prof = nullptr;
+  static int prof_calls = 0;
+  if (getenv("GSV_WIDE_PROF") && !d_prof) { (void)hipMalloc((void**)&d_prof, 64 * 8); (void)hipMemset(d_prof, 0, 64 * 8); }
+  b.prof = d_prof;
   const bool res = a.res != nullptr, acc = a.accumulate != 0;
 #define GSV_WIDE(R, A)                                                                                                     \
   do {                                                                                                                     \
     auto kern = conv_wide_f16_kernel<R, A>;                                                                                \
     static bool set = false;                                                                                               \
     if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, rows_win, ntiles);                                          \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b, rows_win, ntiles);                                          \
   } while (0)
   if (res && acc) GSV_WIDE(true, true);
   else if (res) GSV_WIDE(true, false);
@@ -227,6 +251,14 @@ int launch_conv_wide(int dtype, const ConvArgs& a, hipStream_t s) {
   else GSV_WIDE(false, false);
 #undef GSV_WIDE
   GSV_HIP(hipGetLastError());
+  if (d_prof && ++prof_calls == 3) {
+    (void)hipStreamSynchronize(s);
+    unsigned long long hp[64];
+    (void)hipMemcpy(hp, d_prof, sizeof(hp), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[wide prof] taps %d:", a.taps);
+    for (int i = 1; i < 24 && hp[i]; ++i) fprintf(stderr, " %.2f", (double)(hp[i] - hp[0]) / 100.0);
+    fprintf(stderr, "\n");
+  }
   return GSV_OK;
 }
 

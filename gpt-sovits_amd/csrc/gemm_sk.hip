@@ -33,6 +33,7 @@ __device__ __forceinline__ void row_epilogue(const ConvArgs& a, float (&v)[16], 
   const long long roff = (long long)t * a.ldr + cbase;
   const bool full = nv == 16;
   const bool vec_ok = full && ((a.ldy & 7) == 0) && ((a.y_col0 & 7) == 0) && ((a.ldr & 7) == 0);
+  const bool has_act = a.post_act != ACT_NONE;
   float rr[16];
   if (a.res) {
     if (vec_ok && !a.res_f32) {
@@ -51,7 +52,7 @@ __device__ __forceinline__ void row_epilogue(const ConvArgs& a, float (&v)[16], 
     if (a.gate) u *= a.gate[cbase + e];
     if (a.res) u += rr[e];
     u *= a.scale;
-    v[e] = post_act_f(a.post_act, u);
+    v[e] = has_act ? post_act_f(a.post_act, u) : u;
   }
   if (a.out_f32) {
     float* yp = (float*)a.y + yoff;

