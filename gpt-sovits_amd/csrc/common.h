@@ -1,6 +1,8 @@
 // gsv HIP library -- shared helpers (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -90,7 +92,7 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_LRELU = 3, ACT_MISH = 4, AC
 // accumulate / residual variants 2-3x slower (instruction-cache misses), measured with rocprofv3 on MI355X.
 static __device__ __noinline__ float post_act_slow(int act, float u) {
   switch (act) {
-    case ACT_TANH: return tanhf(u);
+    case ACT_TANH: { const float t = __expf(-2.f * fabsf(u)); return copysignf(__fdividef(1.f - t, 1.f + t), u); }   // = fast_tanh below
     case ACT_MISH: return u * tanhf(u > 20.f ? u : log1pf(expf(u)));   // x * tanh(softplus(x))
     case ACT_SILU: return u / (1.f + expf(-u));
     case ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
@@ -109,6 +111,25 @@ __device__ __forceinline__ float post_act_f(int act, float u) {
   if (act == ACT_RELU20) return fminf(fmaxf(u, 0.f), 20.f);
   return post_act_slow(act, u);
 }
+
+// Epilogue activation with the code fixed at compile time for the two cases that matter for speed (none: every ResBlock
+// conv; tanh: conv_post over 4.1 M samples), -1 = decide per value from the run-time code.  The kernels test the run-time
+// code ONCE per epilogue pass and call the matching instance (conv_wide.hip has the measurement that led here).
+__device__ __forceinline__ float fast_tanh(float u) {
+  const float t = __expf(-2.f * fabsf(u));
+  return copysignf(__fdividef(1.f - t, 1.f + t), u);
+}
+template <int ACTC> __device__ __forceinline__ float post_act_c(int act, float u) {
+  if (ACTC == ACT_NONE) return u;
+  if (ACTC == ACT_TANH) return fast_tanh(u);
+  return post_act_f(act, u);
+}
+#define GSV_ACT_DISPATCH(act, fn)                                         \
+  do {                                                                    \
+    if ((act) == ACT_NONE) fn(std::integral_constant<int, ACT_NONE>{});   \
+    else if ((act) == ACT_TANH) fn(std::integral_constant<int, ACT_TANH>{}); \
+    else fn(std::integral_constant<int, -1>{});                           \
+  } while (0)
 
 struct ConvArgs {
   const void* x = nullptr;   // [Z][T_in][ldx] activations, channels-last

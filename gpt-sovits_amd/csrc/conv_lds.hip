@@ -301,7 +301,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
           float u = av[j] + ebias[j];
           if (RES) u += to_f(rv[RES_LAZY ? e : q][j]);
           u *= a.scale;
-          if (decltype(act_tag)::value) u = post_act_f(a.post_act, u);
+          u = post_act_c<decltype(act_tag)::value>(a.post_act, u);
           if (PRE_ACC) u += to_f(yv[q][j]);
           else if (ACCU) u += to_f(ya[e][j]);
           v[j] = u;
@@ -319,8 +319,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
         }
       }
     };
-    if (a.post_act == ACT_NONE) items(std::false_type{});
-    else items(std::true_type{});
+    GSV_ACT_DISPATCH(a.post_act, items);
     if (RES_LAZY && pass + 1 < WN) load_res_pass(pass + 1);
   }
 }
@@ -484,7 +483,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
           float u = (av[j] + ebias[j]) * egate[j];
           if (RES) u += to_f(rv[q][j]);
           u *= a.scale;
-          if (decltype(act_tag)::value) u = post_act_f(a.post_act, u);
+          u = post_act_c<decltype(act_tag)::value>(a.post_act, u);
           v[j] = u;
         }
         const long long yoff = ybase + (long long)t * a.ldy + a.y_col0 + ec;
@@ -500,8 +499,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
         }
       }
     };
-    if (a.post_act == ACT_NONE) items(std::false_type{});
-    else items(std::true_type{});
+    GSV_ACT_DISPATCH(a.post_act, items);
   }
 }
 
@@ -714,7 +712,7 @@ __global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, in
             float u = av[j] + ebias[j];
             if (RES) u += (float)rv[q][j];
             u *= a.scale;
-            if (decltype(act_tag)::value) u = post_act_f(a.post_act, u);
+            u = post_act_c<decltype(act_tag)::value>(a.post_act, u);
             if (ACCU) u += (float)yv[q][j];
             v[j] = u;
           }
@@ -728,8 +726,7 @@ __global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, in
           }
         }
       };
-      if (a.post_act == ACT_NONE) items(std::false_type{});
-      else items(std::true_type{});
+      GSV_ACT_DISPATCH(a.post_act, items);
     }
     __syncthreads();                 // the fp32 tile (aliasing the window) has been read by every thread
     store_window(nxt);

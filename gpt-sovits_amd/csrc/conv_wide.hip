@@ -182,7 +182,6 @@ __global__ __launch_bounds__(256) void conv_wide_f16_kernel(ConvArgs a, int rows
       // The activation code is a run-time argument: tested per ELEMENT (as the tile kernel does) it cost ~50 scalar
       // instructions and a branch per value -- 6.7 us of a 24 us tile, measured with in-kernel stamps.  Tested once per pass:
       auto items = [&](auto act_tag) {
-        constexpr bool HAS_ACT = decltype(act_tag)::value;
 #pragma unroll
         for (int e = 0; e < NI; ++e) {
           const int tl = (tid + e * NT) / IPR;
@@ -195,15 +194,14 @@ __global__ __launch_bounds__(256) void conv_wide_f16_kernel(ConvArgs a, int rows
             float u = av[j] + ebias[j];
             if (RES) u += (float)rv[e][j];
             u *= a.scale;
-            if (HAS_ACT) u = post_act_f(a.post_act, u);
+            u = post_act_c<decltype(act_tag)::value>(a.post_act, u);
             if (ACCU) u += (float)ya[e][j];
             v[j] = u;
           }
           *(T4*)((T*)a.y + (long long)t * a.ldy + ec) = (T4){(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
         }
       };
-      if (a.post_act == ACT_NONE) items(std::false_type{});
-      else items(std::true_type{});
+      GSV_ACT_DISPATCH(a.post_act, items);
       if (RES && pass + 1 < WN) load_res_pass(pass + 1);
       WSTAMP();
     }

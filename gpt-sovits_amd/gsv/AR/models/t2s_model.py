@@ -117,12 +117,21 @@ class Text2SemanticDecoder:
             lens_h = (C.c_int32 * B)(*lens)
             bert_dev = None
             if bert is not None and any(b_ is not None for b_ in bert):
-                # None = all-zero features (non-zh text): bert_proj(0) is its bias, handled in the engine
-                cols = [(torch.zeros(lens[i], 1024, device=dev) if b_ is None
-                         else b_.reshape(1024, -1).t().to(dev, torch.float32)) for i, b_ in enumerate(bert)]
-                allb = torch.cat(cols, 0).contiguous()
-                if bool(torch.any(allb)):            # one host sync for the whole batch
-                    bert_dev = allb
+                # None or all-zero features (non-zh text): bert_proj(0) is its bias, handled in the engine.  Host tensors are
+                # tested on the host and travel as ONE copy (the pipeline hands over 32 zero blocks of 330 KB per batch: as 32
+                # pageable uploads + a device-side any() + sync they were ~1 ms of idle GPU in front of every prefill)
+                on_host = all(b_ is None or b_.device.type == "cpu" for b_ in bert)
+                if on_host:
+                    if any(b_ is not None and bool(b_.any()) for b_ in bert):
+                        cols = [(torch.zeros(lens[i], 1024) if b_ is None else b_.reshape(1024, -1).t().float())
+                                for i, b_ in enumerate(bert)]
+                        bert_dev = torch.cat(cols, 0).contiguous().to(dev)
+                else:
+                    cols = [(torch.zeros(lens[i], 1024, device=dev) if b_ is None
+                             else b_.reshape(1024, -1).t().to(dev, torch.float32)) for i, b_ in enumerate(bert)]
+                    allb = torch.cat(cols, 0).contiguous()
+                    if bool(torch.any(allb)):            # one host sync for the whole batch
+                        bert_dev = allb
             pr = prompts.to(dev, torch.int32).contiguous()
             out_tokens = torch.zeros(B, budget, dtype=torch.int32, device=dev)
             out_len = torch.full((B,), -1, dtype=torch.int32, device=dev)

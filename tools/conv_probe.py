@@ -17,15 +17,17 @@ SHAPES = [(16, 16, 3, 1, 4096000), (16, 16, 11, 5, 4096000), (32, 32, 7, 3, 2048
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 if len(sys.argv) > 2:            # explicit shapes: CinxCoutxkxdilxT ...
     SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[2:]]
-for (Cin, Cout, k, dil, T) in SHAPES:
+for shape in SHAPES:
+    (Cin, Cout, k, dil, T), post = shape[:5], (shape[5] if len(shape) > 5 else 0)       # optional 6th field: post_act code (2 = tanh)
+    f32out = 1 if Cout == 1 else 0
     x = torch.randn(T, Cin, device=DEV, dtype=torch.float16)
     w = (torch.randn(Cout, k * Cin, device=DEV) / (Cin * k) ** 0.5).half()
     b = torch.randn(Cout, device=DEV)
     r = torch.randn(T, Cout, device=DEV, dtype=torch.float16)
-    y = torch.empty(T, Cout, device=DEV, dtype=torch.float16)
+    y = torch.empty(T, Cout, device=DEV, dtype=torch.float32 if f32out else torch.float16)
     pad = (k * dil - dil) // 2
-    d = _lib.ConvDesc(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), r.data_ptr(), T, T, Cin, Cout, k, 1, dil, pad,
-                      3, 0.1, 0, 1.0, 0, 0, 0, 0)
+    d = _lib.ConvDesc(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None if f32out else r.data_ptr(), T, T, Cin, Cout, k, 1, dil, pad,
+                      3, 0.1, post, 1.0, 0, f32out, 0, 0)
     for _ in range(2):
         _lib.check(_lib.lib().gsv_op_conv1d(C.byref(d), 1, None))
     torch.cuda.synchronize()
