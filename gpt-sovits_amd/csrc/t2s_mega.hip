@@ -147,6 +147,7 @@ struct Ctx {
   gu32* err;
   int hint_miss16;              // hint phase ends when at most this many 16ths of the polled lines are still missing
   int hint_pipe;                // two hint polls in flight (GSV_MEGA_HINT bit 4)
+  bool hopb_compute;            // hop B swept by the compute waves (GSV_MEGA_HINT bit 6)
   unsigned long long* prof;     // this wave's 32 stamp slots or null
   bool prof_on;
 };
@@ -597,8 +598,8 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
       MG_STAMP(q, 5);
       relaunder(q);
       if (kv_more) kv_stage_store(q, kv_extra, kvs);
-      // ---- hop B: attention output of all heads -> AT
-      if (sweeper && ra < R) {
+      // ---- hop B: attention output of all heads -> AT (by the compute waves instead when c.hopb_compute, see there)
+      if (!q.hopb_compute && sweeper && ra < R) {
         unsigned va[4];
         if (sweep<4>(q, q.hop + HOP_B + ra * 256, 256, ep0 + 4 * l + 2, va, 3u, a.hint_mask & 2)) {
           unsigned* at = (unsigned*)(smem + L_AT);
@@ -833,6 +834,17 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         if (r < R && !(e & 1)) gstore(q.hop + HOP_B + r * 256 + (q.head * HD + e) / 2, ep0 + 4 * l + 2, pack_h2(o, o2));
       }
       MG_STAMP(q, 10);
+      if (q.hopb_compute && q.cw < R) {
+        // Hop B is swept by the compute waves, which have nothing to do until it lands: the comm waves cannot poll before
+        // their K/V loads of the next layer have retired (a wave's loads retire in order, ~3.4 us after issue), so with them
+        // the first poll of hop B only LEFT when the K/V burst was over; issued from here it is already in flight by then.
+        unsigned vb[4];
+        if (sweep<4>(q, q.hop + HOP_B + q.cw * 256, 256, ep0 + 4 * l + 2, vb, 3u, a.hint_mask & 2)) {
+          unsigned* at = (unsigned*)(smem + L_AT);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) at[q.cw * (XS_LD / 2) + k * 64 + q.lane] = vb[k];
+        }
+      }
       MG_BAR();                                                          // B4: the attention has released the K/V image
       relaunder(q);
       // ================= P2: out-projection columns [16 member, +16) + bias + residual -> y1
@@ -998,6 +1010,7 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   c.prof_on = false;
   c.hint_miss16 = (a.hint_mask >> 8) & 31;
   c.hint_pipe = (a.hint_mask >> 4) & 1;
+  c.hopb_compute = (a.hint_mask >> 6) & 1;
   const int lane = c.lane, R = c.R;
   const StepParams sp = *a.sp;
 

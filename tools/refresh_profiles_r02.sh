@@ -19,3 +19,15 @@ rm -rf /tmp/pw && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 echo "[prof] WRITE_SIZE pass done"
 ALG=$(python3 -c "import json;print(json.load(open('$O/r02_bench_line.json'))['roofline']['algorithmic_bytes_per_launch'])")
 python3 $R/tools/mega_traffic.py /tmp/pf /tmp/pw $O/r02_mega_traffic.json $ALG
+echo "[prof] PMC reduction done"
+cd $R
+python3 tools/mega_prof.py $O/mega_prof_raw.txt > $O/r02_mega_profile.txt 2>&1
+echo "[prof] engine time line done"
+python3 tools/sample_bench.py > $O/r02_sampling.json 2>$O/sampling.err
+python3 tools/gemm_probe.py 5760x512x1536 5760x512x512 5760x512x2048 5760x2048x512 934x1024x3072 934x1024x1024 934x2048x1024 > $O/r02_gemm_probe.txt 2>&1
+python3 tools/conv_probe.py 10 128x128x3x1x512000 128x128x7x1x512000 128x128x11x5x512000 256x256x11x1x64000 64x64x11x5x1024000 16x1x7x1x4096000x2 > $O/r02_conv_probe.txt 2>&1
+bash tools/trace_sovits.sh > $O/r02_trace_by_grid.txt 2>&1
+echo "[prof] probes done"
+# numbers the parity tests print (agreement rates, measured errors): one pass with -s, lines starting with '['
+python3 -m pytest tests/test_t2s_mega_gpu.py tests/test_frontend_gpu.py tests/test_t2s_gpu.py tests/test_vits_gpu.py tests/test_cfm_gpu.py -q -m gpu -s 2>&1 | grep -a "\[mega\]\|\[frontend\]\|\[t2s\]\|\[vits\]\|\[cfm\]\|passed\|failed" | sed 's/^\.*//' > $O/r02_parity_log.txt || true
+echo "[prof] parity log done"
