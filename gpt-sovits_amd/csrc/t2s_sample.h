@@ -41,14 +41,28 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
 }
 
 struct ArgMax { float v; int i; };
+// (largest value, lowest index on ties) over the wave.  DPP row operations + 4 v_readlane instead of six ds_bpermute
+// butterfly steps on two registers: the extraction loop below calls this once per extracted token, and the shuffle version
+// was most of its ~1.7 us per round (tools/sample_bench.py: top-k 15 cost 35 us per step).
+template <int CTRL> __device__ __forceinline__ void argmax_dpp_step(float& v, int& i) {
+  const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+  const int oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xF, 0xF, true);
+  if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
 __device__ __forceinline__ ArgMax wave_argmax(float v, int i) {
+  argmax_dpp_step<0xB1>(v, i);      // quad_perm [1, 0, 3, 2]
+  argmax_dpp_step<0x4E>(v, i);      // quad_perm [2, 3, 0, 1]
+  argmax_dpp_step<0x141>(v, i);     // row_half_mirror
+  argmax_dpp_step<0x140>(v, i);     // row_mirror: every lane of a 16-lane row now holds the row's result
+  float bv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  int bi = __builtin_amdgcn_readlane(i, 0);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float ov = __shfl_xor(v, o, 64);
-    int oi = __shfl_xor(i, o, 64);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  for (int r = 16; r < 64; r += 16) {
+    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r));
+    const int oi = __builtin_amdgcn_readlane(i, r);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
-  return {v, i};
+  return {bv, bi};
 }
 
 // everything after the repetition penalty: x[] holds the (penalised) logits of this lane's tokens v = lane + 64 i
