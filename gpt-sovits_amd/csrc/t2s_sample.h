@@ -88,6 +88,10 @@ __device__ __forceinline__ void sample_core(float (&x)[NPL], int Veff, int top_k
   if (!use_p && !use_k) {
 #pragma unroll
     for (int i = 0; i < NPL; ++i) if (lane + 64 * i < Veff) keep |= 1u << i;
+  } else if (!use_p && top_k == 1) {
+    // greedy: the kept set is the maximum and its ties (what the extraction below ends with after two rounds, ~3 us)
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) if (lane + 64 * i < Veff && x[i] == max0) keep |= 1u << i;
   } else {
     float S = 1.f;
     if (use_p) {
