@@ -502,8 +502,14 @@ class TTS:
                 return True
             k = id(t)
             if k not in zero_cache:
-                # host tensors: numpy's any() is ~10x cheaper than a torch dispatch per segment
-                zero_cache[k] = not (t.numpy().any() if t.device.type == "cpu" and not t.requires_grad else bool(torch.any(t)))
+                # host tensors: numpy is ~10x cheaper than a torch dispatch per segment, and an integer max over the bit patterns
+                # 3x cheaper than any() (5.5 vs 16.6 us per 330 KB block; -0.0 counts as non-zero, which only forgoes the shortcut)
+                if t.device.type == "cpu" and not t.requires_grad and t.dtype == torch.float32 and t.is_contiguous():
+                    zero_cache[k] = t.numel() == 0 or int(t.numpy().view(np.uint32).max()) == 0
+                elif t.device.type == "cpu" and not t.requires_grad:
+                    zero_cache[k] = not t.numpy().any()
+                else:
+                    zero_cache[k] = not bool(torch.any(t))
             return zero_cache[k]
 
         for index_list in batch_index_list:
