@@ -587,7 +587,11 @@ __global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, in
   static_assert(TT == 256, "tiles are 256 time steps");
   constexpr int LDX = CC + G, VPR = CC / G;
   constexpr int XB = (306 * VPR + NT - 1) / NT;
-  constexpr int LDO = CT + 4, PR = TN * 32, IPR = CT / 4, NI = PR * IPR / NT;   // 64 rows per pass
+  // epilogue passes: as many wave columns per pass as the fp32 tile may take of the window's LDS (the smallest window is 258
+  // rows).  One column per pass meant 2 barriers per column -- 16 per tile at 8 waves; with 128-row passes it is 4.
+  constexpr int WPP = CC == 16 ? 1 : 128 / (TN * 32), NP = WN / WPP;
+  constexpr int LDO = CT + 4, PR = TN * 32 * WPP, IPR = CT / 4, NI = PR * IPR / NT;
+  static_assert(WN % WPP == 0 && (size_t)PR * LDO * 4 <= (size_t)258 * (CC + 8) * 2, "epilogue tile must fit in the smallest window");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = (T*)smem;                                   // [rows_win][LDX]; the epilogue's fp32 [PR][LDO] tile aliases it
   T* ws = xs + (size_t)rows_win * LDX;                // [taps][CT][LDX], staged once
@@ -650,9 +654,9 @@ __global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, in
     // ---- requests for the NEXT tile's window and THIS tile's epilogue operands go out first
     F nxt[XB];
     load_window(min(tile + (int)gridDim.x, ntiles - 1), nxt);
-    T4 rv[RES ? WN * NI : 1], yv[ACCU ? WN * NI : 1];
+    T4 rv[RES ? NP * NI : 1], yv[ACCU ? NP * NI : 1];
 #pragma unroll
-    for (int q = 0; q < ((RES || ACCU) ? WN * NI : 0); ++q) {
+    for (int q = 0; q < ((RES || ACCU) ? NP * NI : 0); ++q) {
       const int pass = q / NI, e = q - pass * NI;
       const int t = min(t0 + pass * PR + (tid + e * NT) / IPR, a.T_out - 1);
       const int cc = min(ec, max(a.Cout - 4, 0));          // clamped channel group: loads stay in bounds; masked by env at use
@@ -685,16 +689,16 @@ __global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, in
     }
     // ---- epilogue through LDS (whole channels-last rows per store), one wave column per pass
 #pragma unroll
-    for (int pass = 0; pass < WN; ++pass) {
+    for (int pass = 0; pass < NP; ++pass) {
       __syncthreads();
-      if (wn == pass) {
+      if (wn / WPP == pass) {
 #pragma unroll
         for (int m = 0; m < TM; ++m)
 #pragma unroll
           for (int n = 0; n < TN; ++n)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-              *(f4*)(os + (size_t)(n * 32 + r) * LDO + m * 32 + 8 * g + 4 * h) =
+              *(f4*)(os + (size_t)(((wn % WPP) * TN + n) * 32 + r) * LDO + m * 32 + 8 * g + 4 * h) =
                   (f4){acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
       }
       __syncthreads();

@@ -40,13 +40,15 @@ __global__ __launch_bounds__(256, CC == 32 ? 2 : 3) void conv_pair_f16_kernel(Co
   constexpr int G = 8, KC = 16, CT = 32, WN = 4, TN = 2, NT = 256;
   constexpr int LDX = CC + G, VPR = CC / G;
   constexpr int XB = (ROWS_X * VPR + NT - 1) / NT;
-  constexpr int LDO = CT + 4, PR = TN * 32, IPR = CT / 4, NI = PR * IPR / NT;     // 64 rows per epilogue pass
+  // epilogue passes of 128 (C = 16) / 256 (C = 32) rows: the fp32 tile may take the window AND the intermediate image by then
+  constexpr int WPP = CC == 16 ? 2 : 4, NP = WN / WPP;
+  constexpr int LDO = CT + 4, PR = TN * 32 * WPP, IPR = CT / 4, NI = PR * IPR / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = (T*)smem;                                   // [ROWS_X][LDX]; the epilogue's fp32 [PR][LDO] tile aliases it
   T* ys = xs + (size_t)ROWS_X * LDX;                  // [ROWS_Y][LDX] lrelu(convs1(...)) of this tile
   T* w2s = ys + (size_t)ROWS_Y * LDX;                 // [TAPS][CT][LDX] convs2's weights; convs1's live in registers (below)
   float* os = (float*)smem;
-  static_assert(PR * LDO * 4 <= ROWS_X * LDX * 2, "epilogue tile must fit in the window");
+  static_assert(PR * LDO * 4 <= (ROWS_X + ROWS_Y) * LDX * 2, "epilogue tile must fit in window + intermediate image");
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const T* __restrict__ x = a.x;
@@ -118,9 +120,9 @@ __global__ __launch_bounds__(256, CC == 32 ? 2 : 3) void conv_pair_f16_kernel(Co
     // ---- requests for the NEXT tile's window and THIS tile's epilogue operands go out first
     F nxt[XB];
     load_window(min(tile + (int)gridDim.x, ntiles - 1), nxt);
-    T4 rv[WN * NI], yv[ACCU ? WN * NI : 1];
+    T4 rv[NP * NI], yv[ACCU ? NP * NI : 1];
 #pragma unroll
-    for (int q = 0; q < WN * NI; ++q) {
+    for (int q = 0; q < NP * NI; ++q) {
       const int pass = q / NI, e = q - pass * NI;
       const int t = min(t0 + pass * PR + (tid + e * NT) / IPR, a.T - 1);
       const int cc = min(ec, CC - 4);
@@ -178,14 +180,14 @@ __global__ __launch_bounds__(256, CC == 32 ? 2 : 3) void conv_pair_f16_kernel(Co
     }
     // ---- epilogue through LDS (whole channels-last rows per store), one wave column per pass
 #pragma unroll
-    for (int pass = 0; pass < WN; ++pass) {
+    for (int pass = 0; pass < NP; ++pass) {
       __syncthreads();
-      if (wn == pass) {
+      if (wn / WPP == pass) {
 #pragma unroll
         for (int n = 0; n < TN; ++n)
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            *(f4*)(os + (size_t)(n * 32 + r) * LDO + 8 * g + 4 * h) =
+            *(f4*)(os + (size_t)(((wn % WPP) * TN + n) * 32 + r) * LDO + 8 * g + 4 * h) =
                 (f4){acc2[n][4 * g], acc2[n][4 * g + 1], acc2[n][4 * g + 2], acc2[n][4 * g + 3]};
       }
       __syncthreads();
