@@ -651,6 +651,10 @@ __global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, in
   __syncthreads();
   for (; tile < ntiles; tile += gridDim.x) {
     const int t0 = tile * TT;
+    const bool pf = a.prof && blockIdx.x == 100 && tile == 100 + 3 * (int)gridDim.x && tid == 0;
+    int pi = 0;
+#define NSTAMP() do { if (pf) a.prof[pi++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    NSTAMP();
     // ---- requests for the NEXT tile's window and THIS tile's epilogue operands go out first
     F nxt[XB];
     load_window(min(tile + (int)gridDim.x, ntiles - 1), nxt);
@@ -663,6 +667,7 @@ __global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, in
       if (RES) rv[q] = *(const T4*)((const T*)a.res + (long long)t * a.ldr + cc);
       if (ACCU) yv[q] = *(const T4*)((const T*)a.y + (long long)t * a.ldy + a.y_col0 + cc);
     }
+    NSTAMP();
     f16v acc[TM][TN];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -687,10 +692,12 @@ __global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, in
           for (int n = 0; n < TN; ++n) mma32l(acc[m][n], af[m], bf[n]);
       }
     }
+    NSTAMP();
     // ---- epilogue through LDS (whole channels-last rows per store), one wave column per pass
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
       __syncthreads();
+      NSTAMP();
       if (wn / WPP == pass) {
 #pragma unroll
         for (int m = 0; m < TM; ++m)
@@ -701,7 +708,9 @@ __global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, in
               *(f4*)(os + (size_t)(((wn % WPP) * TN + n) * 32 + r) * LDO + m * 32 + 8 * g + 4 * h) =
                   (f4){acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
       }
+      NSTAMP();
       __syncthreads();
+      NSTAMP();
       auto items = [&](auto act_tag) {      // activation code tested once per pass, not per element
   #pragma unroll
         for (int e = 0; e < NI; ++e) {
@@ -732,9 +741,12 @@ __global__ __launch_bounds__(64 * WN) void conv_narrow_f16_kernel(ConvArgs a, in
       };
       GSV_ACT_DISPATCH(a.post_act, items);
     }
+    NSTAMP();
     __syncthreads();                 // the fp32 tile (aliasing the window) has been read by every thread
+    NSTAMP();
     store_window(nxt);
     __syncthreads();
+    NSTAMP();
   }
 }
 
@@ -748,12 +760,17 @@ static int launch_narrow(const ConvArgs& a, int rows_win, hipStream_t s) {
   const int per_cu = std::max(1, std::min(cap, (int)((156 * 1024) / lds)));
   const int grid = std::min(ntiles, 256 * per_cu);
   const bool res = a.res != nullptr, acc = a.accumulate != 0;
+  static unsigned long long* d_prof = nullptr;          // measurement runs (GSV_NARROW_PROF=1): in-kernel stamps of one tile
+  static int prof_calls = 0;
+  if (getenv("GSV_NARROW_PROF") && !d_prof) { (void)hipMalloc((void**)&d_prof, 64 * 8); (void)hipMemset(d_prof, 0, 64 * 8); }
+  ConvArgs ap = a;
+  ap.prof = d_prof;
 #define GSV_NARROW(R, A)                                                                                                   \
   do {                                                                                                                     \
     auto kern = conv_narrow_f16_kernel<CC, TM, TN, WN, R, A>;                                                                         \
     static bool set = false;                                                                                               \
     if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN), lds, s, a, rows_win, ntiles);                                          \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN), lds, s, ap, rows_win, ntiles);                                         \
   } while (0)
   if (res && acc) GSV_NARROW(true, true);
   else if (res) GSV_NARROW(true, false);
@@ -761,6 +778,14 @@ static int launch_narrow(const ConvArgs& a, int rows_win, hipStream_t s) {
   else GSV_NARROW(false, false);
 #undef GSV_NARROW
   GSV_HIP(hipGetLastError());
+  if (d_prof && ++prof_calls == 3) {
+    (void)hipStreamSynchronize(s);
+    unsigned long long hp[64];
+    (void)hipMemcpy(hp, d_prof, sizeof(hp), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[narrow prof] C %d taps %d (start | requests issued | taps done | epilogue done | barrier | window stored):", CC, a.taps);
+    for (int i = 1; i < 20 && hp[i]; ++i) fprintf(stderr, " %.2f", (double)(hp[i] - hp[0]) / 100.0);
+    fprintf(stderr, "\n");
+  }
   return GSV_OK;
 }
 
