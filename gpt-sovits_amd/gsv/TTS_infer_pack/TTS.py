@@ -310,10 +310,10 @@ class TTS:
                          norm_text: str = "", ref_mel: Optional[torch.Tensor] = None,
                          sv_emb: Optional[Sequence[torch.Tensor]] = None):
         """`ref_mel` (v3/v4 only): the log-mel of the reference audio as `mel_fn` / `mel_fn_v4` return it ([1, 100, Tm],
-        TTS.py:67-88, 1453) -- computing it from the waveform is part of the audio front-end, outside this build."""
+        TTS.py:67-88, 1453); `set_ref_audio` computes it from the waveform (`mel_fn` / `mel_fn_v4`), this is the model-level entry."""
         self.prompt_cache["ref_mel"] = ref_mel
         # v2Pro / v2ProPlus: one speaker-verification embedding [1, 20480] per reference spectrogram (reference sv.py:11-32,
-        # TTS.py:790-800 keeps it beside the spectrogram); computing it is the ERes2NetV2 front-end, outside this build
+        # TTS.py:790-800 keeps it beside the spectrogram); `set_ref_audio` computes it with gsv.sv.SV (ERes2NetV2)
         self.prompt_cache["sv_emb"] = list(sv_emb) if sv_emb is not None else None
         self.prompt_cache["prompt_semantic"] = prompt_semantic.to(self.configs.device) if prompt_semantic is not None else None
         # the spectrograms go to the device ONCE here (the engine caches the style vector per reference and keys the
