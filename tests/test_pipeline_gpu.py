@@ -226,3 +226,46 @@ def test_audio_postprocess_kernel_matches_reference_arithmetic(half):
     nan_at = np.isnan(ref)
     assert out.shape == ref16.shape and np.array_equal(out[~nan_at], ref16[~nan_at])
     assert tts.last_fragment_lengths == [n + gap for n in lens]
+
+
+def test_sharded_stream_of_a_long_job_on_one_gpu():
+    """BASELINE configs[2] / [4] code path on one GPU (world size 1; the multi-rank exchange is covered by the gloo tests):
+    11 segments -> length-sorted batches of 4 through the work queue -> fragments come back in submission order, equal to a
+    direct TTS.run of each batch, and `wire.streaming_generator` frames them as one wav header + raw chunks."""
+    from gsv import sharding, wire
+    tts, tcfg, tsd, vcfg, vsd = _build()
+    utt = S.make_utterances(11, prompt_phones=6, target_phones=9, prompt_tokens=8, seed=5, ragged=True)
+    refer = S.make_refer_spec(frames=30, seed=5)
+    tts.set_prompt_cache(utt["prompt_semantic"], [refer.to(DEV)], phones=utt["prompt_phones"], bert_features=torch.zeros(1024, 6),
+                         norm_text="xxxxxx")
+    segs = [{"phones": it["phones"], "bert_features": torch.zeros(1024, len(it["phones"])), "norm_text": "x" * (3 + (7 * i) % 5)}
+            for i, it in enumerate(utt["items"])]
+    params = dict(batch_size=4, top_k=1, seed=0, split_bucket=True, parallel_infer=True, fragment_interval=0.01)
+
+    def synth(batch):
+        out = None
+        for sr, audio in tts.run(dict(params, segments=batch)):
+            out = audio
+        return out, list(tts.last_fragment_lengths)
+
+    sh = sharding.ShardedSynthesizer(synth, torch.device(DEV))
+    got = {}
+    order = []
+    for idxs, frags in sh.run_stream(segs, batch_size=4):
+        order.append(list(idxs))
+        for i, f in zip(idxs, frags):
+            got[i] = f
+    batches = sharding.make_batches([len(s["norm_text"]) for s in segs], 4)
+    assert order == batches and sorted(got) == list(range(11))
+    for b in batches:                                           # every batch equals a direct run of the same segments
+        ref, lens = synth([segs[i] for i in b])
+        o = 0
+        for i, n in zip(b, lens):
+            assert np.array_equal(got[i], ref[o:o + n])
+            o += n
+    whole = sh.run(segs, batch_size=4)
+    assert whole.dtype == np.int16 and whole.size == sum(len(got[i]) for i in range(11))
+    assert np.array_equal(whole, np.concatenate([got[i] for i in range(11)]))
+    chunks = list(wire.streaming_generator(((32000, np.concatenate(fr)) for _, fr in sh.run_stream(segs, batch_size=4)), "wav"))
+    assert chunks[0][:4] == b"RIFF" and len(chunks[0]) == 44 and len(chunks) == 1 + len(batches)
+    assert b"".join(chunks[1:]) == np.concatenate([got[i] for b in batches for i in b]).tobytes()
