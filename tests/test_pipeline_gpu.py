@@ -269,3 +269,37 @@ def test_sharded_stream_of_a_long_job_on_one_gpu():
     chunks = list(wire.streaming_generator(((32000, np.concatenate(fr)) for _, fr in sh.run_stream(segs, batch_size=4)), "wav"))
     assert chunks[0][:4] == b"RIFF" and len(chunks[0]) == 44 and len(chunks) == 1 + len(batches)
     assert b"".join(chunks[1:]) == np.concatenate([got[i] for b in batches for i in b]).tobytes()
+
+
+def test_return_fragment_streams_batches_and_http_seam():
+    """`return_fragment` (TTS.py:1321-1330): one yield per batch in submission order (bucketing off, as the reference forces), whose
+    concatenation equals the one-shot result with split_bucket=False; and `wire.tts_handle` in streaming mode on the real pipeline:
+    44-byte wav header chunk, then the same samples as raw chunks; a failing request behaves as in the reference."""
+    from gsv import wire
+    tts, *_ = _build()
+    utt = S.make_utterances(5, prompt_phones=6, target_phones=9, prompt_tokens=8, seed=9, ragged=True)
+    refer = S.make_refer_spec(frames=30, seed=5)
+    tts.set_prompt_cache(utt["prompt_semantic"], [refer.to(DEV)], phones=utt["prompt_phones"], bert_features=torch.zeros(1024, 6),
+                         norm_text="xxxxxx")
+    segs = [{"phones": it["phones"], "bert_features": torch.zeros(1024, len(it["phones"])), "norm_text": "x" * (4 + i)}
+            for i, it in enumerate(utt["items"])]
+    req = dict(segments=segs, batch_size=2, top_k=1, seed=0, fragment_interval=0.01, parallel_infer=True)
+    parts = list(tts.run(dict(req, return_fragment=True)))
+    assert len(parts) == 3 and all(sr == 32000 and a.dtype == np.int16 for sr, a in parts)
+    sr, whole = list(tts.run(dict(req, split_bucket=False)))[-1]
+    assert np.array_equal(np.concatenate([a for _, a in parts]), whole)
+    code, mt, it = wire.tts_handle(tts, dict(req, streaming_mode=True, media_type="wav"))
+    chunks = list(it)
+    assert code == 200 and mt == "audio/wav" and len(chunks) == 4 and len(chunks[0]) == 44 and chunks[0][:4] == b"RIFF"
+    assert b"".join(chunks[1:]) == whole.tobytes()
+    code, mt, body = wire.tts_handle(tts, dict(req, media_type="raw", split_bucket=False))
+    assert code == 200 and body == whole.tobytes()
+    tts.prompt_cache["prompt_semantic"] = None
+    tts.prompt_cache["refer_spec"] = []
+    # a failing request: TTS.run yields one second of silence and raises on the NEXT item (TTS.py:1352-1363); the reference's
+    # non-streaming handler only takes the first item (api_v2.py:356-358), so it answers 200 with that silence -- mirrored
+    code, mt, body = wire.tts_handle(tts, dict(req, media_type="raw"))
+    assert code == 200 and body == bytes(32000)
+    code, mt, it = wire.tts_handle(tts, dict(req, streaming_mode=True, media_type="raw"))
+    with pytest.raises(Exception):
+        list(it)
