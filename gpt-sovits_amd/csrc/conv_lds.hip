@@ -350,7 +350,8 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
   int bx = blockIdx.x, by = blockIdx.y;
   if (gridDim.z == 1 && a.xcd_order) {
     const int vid = xcd_virtual_id(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    bx = vid % gridDim.x; by = vid / gridDim.x;
+    if (a.xcd_order == 2) { by = vid % gridDim.y; bx = vid / gridDim.y; }      // an XCD gets all column tiles of a band of ROW tiles
+    else { bx = vid % gridDim.x; by = vid / gridDim.x; }
   }
   const int t0 = bx * TT, cout0 = by * CT;
   const int z = blockIdx.z;                            // batch (attention heads): operand / output offsets
@@ -516,6 +517,13 @@ template <typename T> static int try_launch_gemm(const ConvArgs& a, hipStream_t 
   static const bool xcd = !(getenv("GSV_GEMM_XCD") && getenv("GSV_GEMM_XCD")[0] == '0');     // A/B switch
   ConvArgs b = a;
   b.xcd_order = xcd ? 1 : 0;
+  // Which operand an XCD's L2 should keep: every tile streams one activation panel [128][K] and one weight panel [128][K].
+  // Order 1 gives an XCD a band of weight panels (all row tiles of a few column tiles); when the activations are the larger
+  // operand and ALL weights fit an L2 anyway (prefill: 5760 x 2048 activations = 23.6 MB against 2 MB of weights), order 2 gives
+  // it a band of row tiles with all their column tiles, so that an activation panel is fetched from memory once per XCD
+  // instead of once per column tile (tools/gemm_probe.py, GSV_GEMM_XCD=1 restores order 1).
+  static const bool only1 = getenv("GSV_GEMM_XCD") && getenv("GSV_GEMM_XCD")[0] == '1';
+  if (xcd && !only1 && (long long)a.T_virt > 2LL * a.Cout && (size_t)a.Cout * a.Cin * sizeof(T) <= (size_t)3 << 20) b.xcd_order = 2;
   if (a.res) {
     auto kern = gemm_lds_kernel<T, true>;
     static bool set = false;
