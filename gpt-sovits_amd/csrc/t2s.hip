@@ -1524,7 +1524,7 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
       a.nsteps = budget - 1; a.map_shared = map_local ? 0 : 1;
       // bits 0-3: hops (A, B, C, D) that poll one granule per line first; bits 8-12: 16ths of the lines that may still be
       // missing when the full passes start
-      static const int hint_mask = getenv("GSV_MEGA_HINT") ? atoi(getenv("GSV_MEGA_HINT")) : (15 | (2 << 8));   // bit 4 (two polls in flight): 3 % slower; bit 5 (payload through L2, needs GSV_MEGA_RING > 1): no gain
+      static const int hint_mask = getenv("GSV_MEGA_HINT") ? atoi(getenv("GSV_MEGA_HINT")) : (15 | (2 << 8) | (6 << 13));   // bits 13-15: poll every 2^n-th payload line (6: one line per row)   // bit 4 (two polls in flight): 3 % slower; bit 5 (payload through L2, needs GSV_MEGA_RING > 1): no gain
       a.hint_mask = hint_mask;
       a.ring = m.ring;
       m.launch_gen = (m.launch_gen + 1) & 2047;

@@ -147,6 +147,7 @@ struct Ctx {
   gu32* err;
   int hint_miss16;              // hint phase ends when at most this many 16ths of the polled lines are still missing
   int hint_pipe;                // two hint polls in flight (GSV_MEGA_HINT bit 4)
+  int hint_stride;              // poll every n-th payload line (1, 2, 4, 8)
   bool hopb_compute;            // hop B swept by the compute waves (GSV_MEGA_HINT bit 6)
   unsigned long long* prof;     // this wave's 32 stamp slots or null
   bool prof_on;
@@ -326,8 +327,11 @@ __device__ __forceinline__ bool sweep_wide(const Ctx& c, gu64* g, unsigned epoch
   constexpr int NLINES = NQ * 8;                       // 16 granules per 128-byte line
   if (hint) {                                          // as in sweep2: the last granule of every line first
     for (unsigned spins = 0;; ++spins) {
-      const bool miss = c.lane < NLINES && (unsigned)(gload(g + min(c.lane, NLINES - 1) * 16 + 15) >> 32) != epoch;
-      if (__popcll(__ballot(miss)) * 16 <= NLINES * c.hint_miss16) break;
+      // every hint_stride-th line only (GSV_MEGA_HINT bits 13-14): fewer requests per poll, a weaker hint
+      const int np = max(1, NLINES / c.hint_stride);
+      const int ln = min(min(c.lane, np - 1) * c.hint_stride + c.hint_stride - 1, NLINES - 1);
+      const bool miss = c.lane < np && (unsigned)(gload(g + ln * 16 + 15) >> 32) != epoch;
+      if (__popcll(__ballot(miss)) * 16 <= np * c.hint_miss16) break;
       if (spins > SPIN_MAX || *st_abort(c) || (spins & 1023u) == 1023u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
         mega_fail(c, epoch, code | 0x100u);
         return false;
@@ -1065,6 +1069,7 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   c.prof_on = false;
   c.hint_miss16 = (a.hint_mask >> 8) & 31;
   c.hint_pipe = (a.hint_mask >> 4) & 1;
+  c.hint_stride = 1 << ((a.hint_mask >> 13) & 7);
   c.hopb_compute = (a.hint_mask >> 6) & 1;
   const int lane = c.lane, R = c.R;
   const StepParams sp = *a.sp;
