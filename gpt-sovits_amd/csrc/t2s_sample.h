@@ -65,6 +65,14 @@ __device__ __forceinline__ ArgMax wave_argmax(float v, int i) {
   return {bv, bi};
 }
 
+// order-preserving map float -> unsigned (a > b <=> key(a) > key(b)); -0 and +0 share a key like they compare equal,
+// NaN sorts below everything (the extraction loop never picks a NaN either)
+__device__ __forceinline__ unsigned ordered_key(float x) {
+  unsigned b = __float_as_uint(x);
+  if (b == 0x80000000u) b = 0u;
+  return x != x ? 0u : (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
 // everything after the repetition penalty: x[] holds the (penalised) logits of this lane's tokens v = lane + 64 i
 template <int NPL>
 __device__ __forceinline__ void sample_core(float (&x)[NPL], int Veff, int top_k, float top_p, float temperature,
@@ -92,6 +100,27 @@ __device__ __forceinline__ void sample_core(float (&x)[NPL], int Veff, int top_k
     // greedy: the kept set is the maximum and its ties (what the extraction below ends with after two rounds, ~3 us)
 #pragma unroll
     for (int i = 0; i < NPL; ++i) if (lane + 64 * i < Veff && x[i] == max0) keep |= 1u << i;
+  } else if (!use_p) {
+    // top-k alone (the reference's CLI / API / web UI defaults leave top_p at 1): the k-th largest value by a radix select
+    // on order-preserving integer keys -- 32 rounds of NPL compares whose wave-wide count is one s_bcnt1 on the compare
+    // mask each, no cross-lane reduction, no dependence on k, and done as soon as a prefix separates exactly k values (the extraction loop below costs ~1.45 us per extracted
+    // token: 32 us per step at top-k 15, 125 us at top-k 100; tools/sample_bench.py).  Keeps exactly the set the loop
+    // keeps: values >= the k-th largest (ties kept, utils.py:171-174), never -inf.
+    unsigned key[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) key[i] = lane + 64 * i < Veff ? ordered_key(x[i]) : 0u;
+    unsigned thr = 0u;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned cand = thr | (1u << bit);
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) cnt += __builtin_popcountll(__ballot(key[i] >= cand));
+      if (cnt >= top_k) thr = cand;
+      if (cnt == top_k) break;      // exactly k values >= cand: that IS the kept set (a tie at the k-th value never counts k)
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) if (key[i] >= thr && x[i] > -INFINITY && lane + 64 * i < Veff) keep |= 1u << i;
   } else {
     float S = 1.f;
     if (use_p) {
@@ -140,13 +169,19 @@ __device__ __forceinline__ void sample_core(float (&x)[NPL], int Veff, int top_k
   for (int i = 0; i < NPL; ++i) if ((keep >> i) & 1u) z += expf(x[i] / tdiv - lm);
   z = wave_sum(z);
   float sv = -INFINITY; int si = 0x7fffffff;
+  // filtered-out tokens have p = 0 and score 0 / q = 0: they can only win when no kept token has a positive score, which
+  // cannot happen (rank 0 is always kept), so their Exp(1) draw is never needed.  Each lane walks ITS kept tokens (lowest
+  // first): the wave runs max-over-lanes popcount(keep) bodies -- 1-2 for top-k 15 -- where a loop over the NPL slots ran
+  // one body per slot that any lane kept (13 of 17 at top-k 15: 0.5 us each, tools/sample_bench.py).
+  unsigned int todo = keep;
+  while (todo) {
+    const int i = __ffs(todo) - 1;
+    todo &= todo - 1;
+    float xi = x[0];
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) {
+    for (int j = 1; j < NPL; ++j) xi = i == j ? x[j] : xi;
     const int v = lane + 64 * i;
-    // filtered-out tokens have p = 0 and score 0 / q = 0: they can only win when no kept token has a
-    // positive score, which cannot happen (rank 0 is always kept), so their Exp(1) draw is never needed
-    if (v >= Veff || !((keep >> i) & 1u)) continue;
-    float p = expf(x[i] / tdiv - lm) / z;
+    float p = expf(xi / tdiv - lm) / z;
     float qn;
     if (noise_row) qn = noise_row[v];
     else {

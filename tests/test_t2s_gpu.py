@@ -89,13 +89,21 @@ def test_sampling_kernel_matches_oracle():
     dev = "cuda:0"
     for V, B, prev_len in [(1025, 16, 40), (65, 8, 12), (1025, 4, 300)]:
         for (top_k, top_p, temp, rp) in [(1, 1.0, 1.0, 1.35), (5, 1.0, 1.0, 1.35), (15, 0.9, 0.8, 1.35),
-                                          (0, 0.7, 1.3, 1.0), (0, 1.0, 1.0, 1.2), (20, 0.99, 1e-6, 1.35)]:
+                                          (0, 0.7, 1.3, 1.0), (0, 1.0, 1.0, 1.2), (20, 0.99, 1e-6, 1.35),
+                                          (15, 1.0, 0.8, 1.35), (100, 1.0, 1.0, 1.2), (2, 1.0, 1.0, 1.0)]:
             logits = torch.randn(B, V) * 3
             if top_p >= 1.0:
                 # coarse grid -> ties exist: top-k keeps every value tied with the k-th (utils.py:183-186).
                 # (with top_p < 1 the kept set inside a tie group depends on torch.sort's unspecified
                 # tie order, so those cases use tie-free logits)
                 logits = logits.round(decimals=1)
+                # top-k alone runs the radix select on integer keys: masked tokens, both zeros and a k that exceeds the
+                # number of finite values must give the kept set of torch.topk + `logits < pivot`
+                logits[:, 3] = -float("inf")
+                logits[:, 5] = -0.0
+                logits[:, 7] = 0.0
+                if top_k == 100 and B == 4:
+                    logits[:, 50:] = -float("inf")
             prev = torch.randint(0, V - 1, (B, prev_len))
             noise = torch.empty(B, V).exponential_(1).clamp_min(1e-10)
             Veff = V - 1
