@@ -142,6 +142,20 @@ def extra_v3(dev, n_steps=32, frames=934, prompt=468):
         wav = voc(mel[:, :, prompt:].clamp(-12, 2))
         torch.cuda.synchronize(); t2 = time.perf_counter()
         best_c, best_v = min(best_c, t1 - t0), min(best_v, t2 - t1)
+    # the pipeline's batched path (TTS.using_vocoder_synthesis_batched_infer, reference TTS.py:1496-1609): the chunks of a
+    # batch of segments go through ONE batched cfm.inference and are vocoded as one sequence
+    NB = 8
+    mu8 = mu.expand(NB, -1, -1).contiguous()
+    cfm.inference(mu8, None, pr, 2, seed=1)
+    best_c8, best_v8 = 1e9, 1e9
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        mel8 = cfm.inference(mu8, None, pr, n_steps, seed=1)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        m8 = mel8[:, :, prompt:].clamp(-12, 2).permute(1, 0, 2).contiguous().view(1, mel8.shape[1], -1)
+        wav8 = voc(m8)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        best_c8, best_v8 = min(best_c8, t1 - t0), min(best_v8, t2 - t1)
     D, inner, FF = cfg["dim"], cfg["heads"] * cfg["dim_head"], cfg["dim"] * cfg["ff_mult"]
     fl = cfg["depth"] * (2 * frames * (D * 3 * inner + inner * D + 2 * D * FF) + 4 * frames * frames * inner) \
         + 2 * 2 * frames * D * (D // 16) * 31 + 2 * frames * (2 * 100 + cfg["text_dim"]) * D + 2 * frames * D * 100
@@ -152,7 +166,14 @@ def extra_v3(dev, n_steps=32, frames=934, prompt=468):
             "dit_tflops": round(fl * n_steps / best_c / 1e12, 1), "dit_frac_mfma": round(fl * n_steps / best_c / 2.5e15, 4),
             "vocoder_ms": round(1e3 * best_v, 2), "vocoder_tflops": round(1.80e9 * new / best_v / 1e12, 1),
             "audio_s_per_chunk": round(audio_s, 3), "value": round(audio_s / (best_c + best_v), 2), "unit": "audio_s/s",
-            "finite": bool(torch.isfinite(wav).all())}
+            "finite": bool(torch.isfinite(wav).all()),
+            "batched_chunks": {"chunks": NB, "cfm_ms_per_euler_step": round(1e3 * best_c8 / n_steps, 3),
+                               "dit_tflops": round(NB * fl * n_steps / best_c8 / 1e12, 1),
+                               "dit_frac_mfma": round(NB * fl * n_steps / best_c8 / 2.5e15, 4),
+                               "vocoder_ms": round(1e3 * best_v8, 2),
+                               "value": round(NB * audio_s / (best_c8 + best_v8), 2), "unit": "audio_s/s",
+                               "finite": bool(torch.isfinite(wav8).all()),
+                               "what": "8 chunks in one batched cfm.inference + one vocoder pass (the pipeline's parallel_infer path)"}}
 
 
 def extra_cold_prompt(tts, dev):
