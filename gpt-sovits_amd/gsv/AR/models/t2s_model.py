@@ -14,6 +14,7 @@ import math
 import warnings
 from typing import Dict, List, Optional, Sequence
 
+import numpy as np
 import torch
 
 from ... import _lib
@@ -28,6 +29,14 @@ def _sine_pe(n_pos: int, dim: int) -> torch.Tensor:
     pe[:, 0::2] = torch.sin(position * div_term)
     pe[:, 1::2] = torch.cos(position * div_term)
     return pe
+
+
+def _host_nonzero(t: torch.Tensor) -> bool:
+    """any(t != 0) for a host tensor without a torch dispatch (bfloat16 has no numpy view: torch then)"""
+    try:
+        return bool(np.any(t.detach().numpy()))
+    except (TypeError, RuntimeError):
+        return bool(t.any())
 
 
 class Text2SemanticDecoder:
@@ -122,7 +131,9 @@ class Text2SemanticDecoder:
                 # pageable uploads + a device-side any() + sync they were ~1 ms of idle GPU in front of every prefill)
                 on_host = all(b_ is None or b_.device.type == "cpu" for b_ in bert)
                 if on_host:
-                    if any(b_ is not None and bool(b_.any()) for b_ in bert):
+                    # numpy on the host view: a torch reduction costs ~1.3 ms per block on a many-core host (thread wake-up), i.e.
+                    # 40 ms per batch of 32 (tools/prefill_probe.py)
+                    if any(b_ is not None and _host_nonzero(b_) for b_ in bert):
                         cols = [(torch.zeros(lens[i], 1024) if b_ is None else b_.reshape(1024, -1).t().float())
                                 for i, b_ in enumerate(bert)]
                         bert_dev = torch.cat(cols, 0).contiguous().to(dev)

@@ -48,6 +48,17 @@ def make_batches(lengths: Sequence[int], batch_size: int) -> List[List[int]]:
     return [order[i:i + batch_size] for i in range(0, len(order), batch_size)]
 
 
+def _nonzero(b) -> bool:
+    """any(b != 0); host data is tested through numpy (a torch reduction per segment costs ~1 ms on a many-core host)"""
+    t = torch.as_tensor(b)
+    if t.device.type == "cpu":
+        try:
+            return bool(np.any(t.detach().numpy()))
+        except (TypeError, RuntimeError):
+            pass
+    return bool(t.any())
+
+
 def pack_segments(segments: List[dict], ship_bert: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """-> (int32 wire [n, has_bert_0.., len_0.., text_len_0.., phones...], float16 BERT blob [1024, sum of shipped columns] or
     None).  All-zero BERT features (every non-zh segment, reference TextPreprocessor.py:216-220) are never shipped: None on the
@@ -58,7 +69,7 @@ def pack_segments(segments: List[dict], ship_bert: bool = True) -> Tuple[torch.T
     has, blobs = [], []
     for s in segments:
         b = s.get("bert_features")
-        nz = b is not None and bool(torch.as_tensor(b).any())
+        nz = b is not None and _nonzero(b)
         if nz and not ship_bert:
             raise ValueError("pack_segments: a segment carries non-zero BERT features (zh text) and ship_bert=False would "
                              "synthesise it as if they were zero")
