@@ -971,7 +971,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
           gstore(q.hop + HOP_D + (q.lane >> 4) * 1024 + 32 * q.member + 16 * q.cw + (q.lane & 15), ep0 + 4 * l + 4, stage[q.lane]);
       }
       relaunder(q);
-      // ================= P4: FFN2 columns [16 member, +16) over K = 2048 (16 chunks, summed in chunk order) -> y2
+      // ================= P4: FFN2 columns [16 member, +16) over K = 2048 (each wave chains its 4 chunks of 128, 4 partials) -> y2
       p_bias = *(const f4*)(lp + FP_B2 + 16 * q.member + 4 * (q.lane >> 4));
       MG_STAMP(q, 19);
       MG_BAR();                                                          // B1: HS holds the FFN hidden
@@ -982,16 +982,18 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
       {
         const int rowl = q.lane & 15, kg = q.lane >> 4;
         f4* red = (f4*)(smem + L_RED);
+        // one accumulator over the wave's four 128-wide chunks (the MFMA forwards a dependent accumulator without a stall):
+        // ONE partial per wave like the other phases, instead of 16 per workgroup through LDS
+        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
           const int kc = 4 * q.cw + cc;
           const _Float16* bp = (const _Float16*)(smem + L_HS) + (rowl & (RMAX - 1)) * HS_LD + kc * 128 + 8 * kg;
-          f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wD[cc * 4 + ks], *(const h8*)(bp + 32 * ks), acc, 0, 0, 0);
-          red[kc * 64 + q.lane] = acc;
           __builtin_amdgcn_sched_barrier(0);       // keep the 16 operand reads from being hoisted in front of the first MFMA
         }
+        red[q.cw * 64 + q.lane] = acc;
       }
       // second half of the next P1 slice: FFN2's slice is dead now, and the request is still in front of the publish
       wload(wA1, p1_src(l + 1 < a.L ? l + 1 : 0) + (size_t)(WI_P1 / 2) * 64);
@@ -1002,15 +1004,10 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         const f4* red = (const f4*)(smem + L_RED);
         const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
         if (r < R) {
-          // all 17 LDS reads first (one at a time each costs a full LDS round trip), then the sum in chunk order
-          f4 part[16];
-#pragma unroll
-          for (int kc = 0; kc < 16; ++kc) part[kc] = red[kc * 64 + q.lane];
+          const f4 v0 = red[q.lane], v1 = red[64 + q.lane], v2 = red[128 + q.lane], v3 = red[192 + q.lane];
           const f4 xr = *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
-          asm volatile("" ::: "memory");
-          f4 v = part[0];
-#pragma unroll
-          for (int kc = 1; kc < 16; ++kc) v += part[kc];
+          f4 v = v0;
+          v += v1; v += v2; v += v3;
           v += p_bias;
           v += xr;
           // y2 feeds hop A of the next layer, or hop A' (the logits' LayerNorm) after the last layer
