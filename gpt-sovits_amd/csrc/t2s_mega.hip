@@ -559,32 +559,43 @@ __device__ __forceinline__ void attention_part(const MegaArgs& a, const Ctx& q, 
 constexpr int KV_T = KV_CAP / 16;            // KiB-instructions per (row, K|V) image = slots per wave (20)
 struct KvStage { h8 r[KV_T]; };
 
+// The row state is read ONCE per call: as written first, every one of the 20 loads sat behind two dependent LDS reads (active,
+// kv_len), a readfirstlane and ~40 scalar address instructions -- the ISA showed the "burst" trickling out over ~3.5 us.
+struct KvRows { int nki[2]; };
+__device__ __forceinline__ KvRows kv_rows(const Ctx& q, int extra) {
+  KvRows k;
+#pragma unroll
+  for (int ro = 0; ro < 2; ++ro) {
+    const int r = 2 * ro + q.half;                   // < RMAX: the state arrays hold RMAX entries
+    const int act = st_active(q)[r], len = st_kvlen(q)[r];
+    k.nki[ro] = __builtin_amdgcn_readfirstlane(r < q.R && act ? (min(len + extra, KV_CAP) + 15) >> 4 : 0);
+  }
+  return k;
+}
+
 __device__ __forceinline__ void kv_stage_load(const MegaArgs& a, const Ctx& q, int layer, int extra, KvStage& st) {
+  const KvRows k = kv_rows(q, extra);
+  const h8* base[2][2];
+#pragma unroll
+  for (int ro = 0; ro < 2; ++ro)
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+      // the arena is allocated to smax positions per (row, head): a partly valid KiB reads allocated memory
+      base[ro][which] = (const h8*)(a.kv + (size_t)(layer * 2 + which) * a.kv_layer_stride +
+                                    ((size_t)(q.group + MG_GROUPS * (2 * ro + q.half)) * NH + q.head) * (size_t)a.smax * HD) + q.lane;
 #pragma unroll
   for (int t = 0; t < KV_T; ++t) {
     const int ro = t / (KV_T / 2), which = (t / (KV_T / 4)) & 1, i = 4 * (t % (KV_T / 4)) + q.cw;
-    const int r = 2 * ro + q.half;
-    if (r < q.R && st_active(q)[r]) {
-      const int nki = (min(st_kvlen(q)[r] + extra, KV_CAP) + 15) >> 4;
-      if (i < nki) {
-        // the arena is allocated to smax positions per (row, head): a partly valid KiB reads allocated memory
-        const _Float16* src = a.kv + (size_t)(layer * 2 + which) * a.kv_layer_stride +
-                              ((size_t)(q.group + MG_GROUPS * r) * NH + q.head) * (size_t)a.smax * HD;
-        st.r[t] = __builtin_nontemporal_load((const h8*)(src + (size_t)i * 16 * HD) + q.lane);
-      }
-    }
+    if (i < k.nki[ro]) st.r[t] = __builtin_nontemporal_load(base[ro][which] + (size_t)i * (16 * HD / 8));
   }
 }
 
 __device__ __forceinline__ void kv_stage_store(const Ctx& q, int extra, const KvStage& st) {
+  const KvRows k = kv_rows(q, extra);
 #pragma unroll
   for (int t = 0; t < KV_T; ++t) {
     const int ro = t / (KV_T / 2), which = (t / (KV_T / 4)) & 1, i = 4 * (t % (KV_T / 4)) + q.cw;
-    const int r = 2 * ro + q.half;
-    if (r < q.R && st_active(q)[r]) {
-      const int nki = (min(st_kvlen(q)[r] + extra, KV_CAP) + 15) >> 4;
-      if (i < nki) *((h8*)(q.smem + L_KV + (ro * 2 + which) * KV_CAP * 64 + i * 1024) + q.lane) = st.r[t];
-    }
+    if (i < k.nki[ro]) *((h8*)(q.smem + L_KV + (ro * 2 + which) * KV_CAP * 64 + i * 1024) + q.lane) = st.r[t];
   }
 }
 
