@@ -858,11 +858,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
           v += p1_bias[it];
           const int ro = r >> 1, which = tile >> 1, e = 16 * (tile & 1) + 4 * (ln >> 4);
           const h4 ov = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-          *(h4*)(qkv_s + (ro * 3 + which) * HD + e) = ov;
-          if (which > 0 && st_active(q)[r]) {
-            const int pos = st_kvlen(q)[r];
-            if (pos < a.smax) *(h4*)(const_cast<_Float16*>(kv_row_base(l, which - 1, r)) + (size_t)pos * HD + e) = ov;
-          }
+          *(h4*)(qkv_s + (ro * 3 + which) * HD + e) = ov;     // the arena append of k, v follows in P2 (see there)
         }
         MG_STAMP(q, 5);
       }
@@ -945,6 +941,18 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         if (q.lane < R * 16)
           gstore(q.hop + HOP_C + (q.lane >> 4) * 512 + 16 * q.member + (q.lane & 15), ep0 + 4 * l + 3,
                  __float_as_uint(((const float*)(smem + L_STAGE))[q.lane]));
+      }
+      if (q.cw == 1 && q.lane < 32) {   // wave 1 is idle while wave 0 publishes
+        // K/V arena append of this step's k, v (own rows), from the LDS copy the attention used.  Not in P1 where they are
+        // produced: there the store has to queue behind the comm waves' K/V burst of the next layer in the CU's memory
+        // pipeline (1.3 us of blocked issue in the stamps); nothing reads the arena row before the next step's staging.
+        const int ro = q.lane >> 4, which = (q.lane >> 3) & 1, e = 4 * (q.lane & 7), r = 2 * ro + q.half;
+        if (r < R && st_active(q)[r]) {
+          const int pos = st_kvlen(q)[r];
+          if (pos < a.smax)
+            *(h4*)(const_cast<_Float16*>(kv_row_base(l, which, r)) + (size_t)pos * HD + e) =
+                *(const h4*)((const _Float16*)(smem + L_QKV) + (ro * 3 + 1 + which) * HD + e);
+        }
       }
       relaunder(q);
       // ================= P3: FFN1 columns [64 member, +64), ReLU -> h
