@@ -148,7 +148,6 @@ struct Ctx {
   int hint_miss16;              // hint phase ends when at most this many 16ths of the polled lines are still missing
   int hint_pipe;                // two hint polls in flight (GSV_MEGA_HINT bit 4)
   int hint_stride;              // poll every n-th payload line (1, 2, 4, 8)
-  bool hopb_compute;            // hop B swept by the compute waves (GSV_MEGA_HINT bit 6)
   unsigned long long* prof;     // this wave's 32 stamp slots or null
   bool prof_on;
 };
@@ -672,8 +671,8 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
       MG_STAMP(q, 5);
       relaunder(q);
       if (kv_more) kv_stage_store(q, kv_extra, kvs);
-      // ---- hop B: attention output of all heads -> AT (by the compute waves instead when c.hopb_compute, see there)
-      if (!q.hopb_compute && sweeper && ra < R) {
+      // ---- hop B: attention output of all heads -> AT
+      if (sweeper && ra < R) {
         u4v qb[2];
         if (sweep_wide<2>(q, q.hop + HOP_B + ra * 256, ep0 + 4 * l + 2, qb, 3u, a.hint_mask & 2)) {
           unsigned* at = (unsigned*)(smem + L_AT) + ra * (XS_LD / 2) + 2 * q.lane;
@@ -868,10 +867,10 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
       MG_STAMP(q, 7);
       attention_part<2>(a, q, l, q.cw);
       MG_STAMP(q, 8);
-      // the partials of a row's two waves meet through LDS: a compute-only barrier, so that the publish below does not wait
-      // for the comm waves, which sit at B4 until their K/V loads of the next layer have landed (~3.4 us after issue: 20 MB per
-      // layer over all CUs, i.e. HBM-bound; that burst, not the arithmetic, is what P1 takes -- A/B of faster arithmetic: no change)
-      compute_barrier(q, cgen);
+      // the partials of a row's two waves meet through LDS.  This barrier is B4 itself (the attention has released the K/V
+      // image): the comm waves only have to ISSUE the next layer's K/V loads before it, which takes ~1.5 us since the row
+      // state is read once per call (it was 3.5 us, and a compute-only barrier stood here so that the publish did not wait)
+      MG_BAR();                                                          // B4
       if (*st_abort(q)) return;
       MG_STAMP(q, 9);
       if (q.cw == 0) {
@@ -895,23 +894,11 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
           }
           o = num / Lsum;
         }
-        const float o2 = __shfl_xor(o, 1, 64);
+        const float o2 = dpp_f<DPP_QUAD_XOR1>(o);            // lane ^ 1
         // 16 granules (one 128-B line) per own row, written by one wave instruction
         if (r < R && !(e & 1)) gstore(q.hop + HOP_B + r * 256 + (q.head * HD + e) / 2, ep0 + 4 * l + 2, pack_h2(o, o2));
       }
       MG_STAMP(q, 10);
-      if (q.hopb_compute && q.cw < R) {
-        // Hop B is swept by the compute waves, which have nothing to do until it lands: the comm waves cannot poll before
-        // their K/V loads of the next layer have retired (a wave's loads retire in order, ~3.4 us after issue), so with them
-        // the first poll of hop B only LEFT when the K/V burst was over; issued from here it is already in flight by then.
-        u4v qb[2];
-        if (sweep_wide<2>(q, q.hop + HOP_B + q.cw * 256, ep0 + 4 * l + 2, qb, 3u, a.hint_mask & 2)) {
-          unsigned* at = (unsigned*)(smem + L_AT) + q.cw * (XS_LD / 2) + 2 * q.lane;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) *(u2v*)(at + j * 128) = (u2v){qb[j][0], qb[j][2]};
-        }
-      }
-      MG_BAR();                                                          // B4: the attention has released the K/V image
       relaunder(q);
       // ================= P2: out-projection columns [16 member, +16) + bias + residual -> y1
       f4 p_bias = *(const f4*)(lp + FP_OUTB + 16 * q.member + 4 * (q.lane >> 4));
@@ -1086,7 +1073,6 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   c.hint_miss16 = (a.hint_mask >> 8) & 31;
   c.hint_pipe = (a.hint_mask >> 4) & 1;
   c.hint_stride = 1 << ((a.hint_mask >> 13) & 7);
-  c.hopb_compute = (a.hint_mask >> 6) & 1;
   const int lane = c.lane, R = c.R;
   const StepParams sp = *a.sp;
 
