@@ -177,13 +177,15 @@ __device__ __forceinline__ void compute_barrier(const Ctx& q, int& gen) {
   asm volatile("" ::: "memory");
 }
 
-__device__ __noinline__ void mega_fail(const Ctx& c, unsigned epoch, unsigned code) {
-  *st_abort(c) = 1;
-  if (c.lane == 0) {
-    __hip_atomic_store(c.err + 1, epoch, RLX_AGENT);
-    __hip_atomic_store(c.err + 2, (unsigned)blockIdx.x, RLX_AGENT);
-    __hip_atomic_store(c.err + 3, code, RLX_AGENT);
-    __hip_atomic_store(c.err, 1u, RLX_AGENT);
+// by value: a `const Ctx&` parameter of a non-inlined function forces the whole Ctx into scratch memory, re-stored at the
+// start of every phase (30 scratch instructions in the hot loops, seen in the ISA)
+__device__ __noinline__ void mega_fail(gu32* err, int lane, unsigned epoch, unsigned code) {
+  *(lds_vint*)((lds_vint*)(unsigned)L_ST + 3 * RMAX) = 1;               // st_abort
+  if (lane == 0) {
+    __hip_atomic_store(err + 1, epoch, RLX_AGENT);
+    __hip_atomic_store(err + 2, (unsigned)blockIdx.x, RLX_AGENT);
+    __hip_atomic_store(err + 3, code, RLX_AGENT);
+    __hip_atomic_store(err, 1u, RLX_AGENT);
   }
 }
 
@@ -232,7 +234,7 @@ __device__ __forceinline__ bool sweep2(const Ctx& c, gu64* g0, gu64* g1, int nva
         issue(pa);
       }
       if (spins > SPIN_MAX || *st_abort(c) || (spins & 1022u) == 1022u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
-        mega_fail(c, epoch, code | 0x100u);
+        mega_fail(c.err, c.lane, epoch, code | 0x100u);
         return false;
       }
     }
@@ -279,7 +281,7 @@ __device__ __forceinline__ bool sweep2(const Ctx& c, gu64* g0, gu64* g1, int nva
     }
     if (__all(ok)) return true;
     if (spins > SPIN_MAX || *st_abort(c) || (spins & 1023u) == 1023u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
-      mega_fail(c, epoch, code);
+      mega_fail(c.err, c.lane, epoch, code);
       return false;
     }
     __builtin_amdgcn_s_sleep(2);
@@ -332,7 +334,7 @@ __device__ __forceinline__ bool sweep_wide(const Ctx& c, gu64* g, unsigned epoch
       const bool miss = c.lane < np && (unsigned)(gload(g + ln * 16 + 15) >> 32) != epoch;
       if (__popcll(__ballot(miss)) * 16 <= np * c.hint_miss16) break;
       if (spins > SPIN_MAX || *st_abort(c) || (spins & 1023u) == 1023u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
-        mega_fail(c, epoch, code | 0x100u);
+        mega_fail(c.err, c.lane, epoch, code | 0x100u);
         return false;
       }
       if (spins < 8) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
@@ -346,7 +348,7 @@ __device__ __forceinline__ bool sweep_wide(const Ctx& c, gu64* g, unsigned epoch
     for (int j = 0; j < NQ; ++j) ok &= q[j][1] == epoch && q[j][3] == epoch;
     if (__all(ok)) return true;
     if (spins > SPIN_MAX || *st_abort(c) || (spins & 1023u) == 1023u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
-      mega_fail(c, epoch, code);
+      mega_fail(c.err, c.lane, epoch, code);
       return false;
     }
     __builtin_amdgcn_s_sleep(2);
