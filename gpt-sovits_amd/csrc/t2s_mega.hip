@@ -826,12 +826,9 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
       q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer;
       MG_STAMP(q, 0);
       // ================= P1: q,k,v of head `head` for the own rows, K/V append, attention
-      f4 p1_bias[2];
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int task = q.tid_c + 256 * it, tile = task >> 6, ln = task & 63;
-        p1_bias[it] = tile < 6 ? *(const f4*)(lp + FP_QKVB + (tile >> 1) * D + q.head * HD + 16 * (tile & 1) + 4 * (ln >> 4)) : (f4){0.f, 0.f, 0.f, 0.f};
-      }
+      // lane j < 24 of every wave reduces 4 values of q | k | v of the wave's OWN attention row (see after B2)
+      const int rj_which = (q.lane >> 3) % 3, rj_e = 4 * (q.lane & 7);
+      const f4 p1_bias = q.lane < 24 ? *(const f4*)(lp + FP_QKVB + rj_which * D + q.head * HD + rj_e) : (f4){0.f, 0.f, 0.f, 0.f};
       MG_STAMP(q, 1);
       MG_BAR();                                                          // B1: XS / XRES hold LN(y)
       if (*st_abort(q)) return;
@@ -845,27 +842,27 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
       if (*st_abort(q)) return;
       MG_STAMP(q, 4);
       {
+        // split-K reduce of q, k, v (+ bias) by the wave that consumes them: each attention wave sums the 96 values of ITS row
+        // (both waves of a row do, and write identical bytes), so that no barrier stands between the reduce and the attention
+        // -- the workgroup-wide reduce + compute-only barrier here were 0.7 us of every layer (stamps 4-7).  Same summation
+        // order as before: ((w0 + w1) + w2) + w3 + bias.
         const f4* red = (const f4*)(smem + L_RED);
         _Float16* qkv_s = (_Float16*)(smem + L_QKV);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int task = q.tid_c + 256 * it, tile = task >> 6, ln = task & 63;
-          const int r = ln & 15;
-          if (tile >= 6 || r >= R || (r & 1) != q.half) continue;
+        const int ro = q.cw / 2, r = 2 * ro + q.half;
+        if (q.lane < 24 && r < R) {
+          const int tile = rj_which * 2 + (rj_e >> 4), ln = r + 16 * ((rj_e & 15) >> 2);
           const f4 v0 = red[(0 * 6 + tile) * 64 + ln], v1 = red[(1 * 6 + tile) * 64 + ln], v2 = red[(2 * 6 + tile) * 64 + ln],
                    v3 = red[(3 * 6 + tile) * 64 + ln];
           f4 v = v0;
           v += v1; v += v2; v += v3;
-          v += p1_bias[it];
-          const int ro = r >> 1, which = tile >> 1, e = 16 * (tile & 1) + 4 * (ln >> 4);
+          v += p1_bias;
           const h4 ov = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-          *(h4*)(qkv_s + (ro * 3 + which) * HD + e) = ov;     // the arena append of k, v follows in P2 (see there)
+          *(h4*)(qkv_s + (ro * 3 + rj_which) * HD + rj_e) = ov;    // the arena append of k, v follows in P2 (see there)
         }
+        asm volatile("" ::: "memory");                      // the attention's reads of qkv_s stay behind the writes (same wave: in order)
         MG_STAMP(q, 5);
       }
       MG_STAMP(q, 6);
-      compute_barrier(q, cgen);                                          // B3 (compute waves only)
-      if (*st_abort(q)) return;
       MG_STAMP(q, 7);
       attention_part<2>(a, q, l, q.cw);
       MG_STAMP(q, 8);
