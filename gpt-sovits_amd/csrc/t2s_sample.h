@@ -100,6 +100,14 @@ __device__ __forceinline__ void sample_core(float (&x)[NPL], int Veff, int top_k
     // greedy: the kept set is the maximum and its ties (what the extraction below ends with after two rounds, ~3 us)
 #pragma unroll
     for (int i = 0; i < NPL; ++i) if (lane + 64 * i < Veff && x[i] == max0) keep |= 1u << i;
+    // a single maximum (no tie): it wins the race whatever the noise, so the softmax and the Exp(1) draw are skipped -- the
+    // sampler sits between the logits hop and the next step's first hop, fully serialised with the step
+    const unsigned long long owners = __ballot(keep != 0u);
+    if (__builtin_popcountll(owners) == 1 &&
+        __builtin_amdgcn_readlane(__builtin_popcount(keep), __builtin_ctzll(owners)) == 1) {
+      *out_sample = am.i;
+      return;
+    }
   } else if (!use_p) {
     // top-k alone (the reference's CLI / API / web UI defaults leave top_p at 1): the k-th largest value by a radix select
     // on order-preserving integer keys -- 32 rounds of NPL compares whose wave-wide count is one s_bcnt1 on the compare
