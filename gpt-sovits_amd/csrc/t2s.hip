@@ -898,6 +898,10 @@ __global__ __launch_bounds__(64) void sample_step_kernel(const float* __restrict
   int smp, amx;
   sample_row<NPL>(logits + (long long)b * V, V, Veff, yrow, prev_len, sp.top_k, sp.top_p, sp.temperature,
                   sp.rep_penalty, nrow, sp.seed, b, step, seen, &smp, &amx);
+  if (sp.dump)
+    for (int v = lane; v < V; v += 64) sp.dump[((long long)step * gridDim.x + b) * V + v] = logits[(long long)b * V + v];
+  if (sp.drawn && lane == 0) { int* dr = sp.drawn + ((long long)step * gridDim.x + b) * 2; dr[0] = smp; dr[1] = amx; }
+  if (sp.force) { smp = sp.force[(long long)b * sp.max_steps + step]; amx = smp; }    // teacher forcing (parity hook)
   const bool fin = (smp == EOS) || (amx == EOS);
   const bool early = (sp.early_stop_num != -1 && (step + 1) > sp.early_stop_num) || (step >= sp.max_steps - 1);
   if (lane == 0) {
@@ -984,6 +988,7 @@ struct gsv_t2s {
   hipEvent_t mega_ev[2] = {nullptr, nullptr};
   float last_decode_ms = 0.f; int last_decode_steps = 0; int last_decode_mode = 0;
   bool mega_on = true;      // gsv_t2s_set_mega (A/B inside one process); GSV_T2S_NO_MEGA=1 never builds the engine
+  const int* dbg_force = nullptr; float* dbg_dump = nullptr; int* dbg_drawn = nullptr; int dbg_stall = 0;   // gsv_t2s_set_debug / gsv_t2s_debug_stall: apply to the NEXT decode call only
   std::map<int, hipGraphExec_t> graphs;
   std::vector<void*> allocs;
 };
@@ -1191,6 +1196,7 @@ int gsv_t2s_finalize(gsv_t2s_t* h) {
     m.hop_bytes = mega_hop_bytes(m.ring);
     GSV_RC(dev_alloc(h, (void**)&m.hop, m.hop_bytes));
     GSV_RC(dev_alloc(h, (void**)&m.err, 64));
+    GSV_RC(dev_alloc(h, (void**)&m.snap, ((size_t)4 * h->max_batch + 4) * 4));
     GSV_HIP(hipHostMalloc((void**)&m.h_err, 64));
     GSV_HIP(hipEventCreate(&h->mega_ev[0]));
     GSV_HIP(hipEventCreate(&h->mega_ev[1]));
@@ -1203,10 +1209,9 @@ int gsv_t2s_finalize(gsv_t2s_t* h) {
   GSV_RC(dev_alloc(h, (void**)&h->d_x_len, B * 4));
   GSV_RC(dev_alloc(h, (void**)&h->d_row_off, B * 4));
   GSV_RC(dev_alloc(h, (void**)&h->d_ph_off, B * 4));
-  GSV_RC(dev_alloc(h, (void**)&h->d_kv_len, B * 4));
-  GSV_RC(dev_alloc(h, (void**)&h->d_active, B * 4));
-  GSV_RC(dev_alloc(h, (void**)&h->d_step, B * 4));
-  GSV_RC(dev_alloc(h, (void**)&h->d_n_active, 16));
+  // one block [kv_len | active | step | n_active]: the persistent engine's fallback saves and restores it with one copy
+  GSV_RC(dev_alloc(h, (void**)&h->d_kv_len, (3 * B + 4) * 4));
+  h->d_active = h->d_kv_len + B; h->d_step = h->d_kv_len + 2 * B; h->d_n_active = h->d_kv_len + 3 * B;
   h->ycap = h->max_seq + 8;
   GSV_RC(dev_alloc(h, (void**)&h->d_ytok, B * h->ycap * 4));
   GSV_RC(dev_alloc(h, (void**)&h->d_sp, sizeof(StepParams)));
@@ -1396,10 +1401,15 @@ int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_le
   GSV_HIP(hipMemcpyAsync(h->d_x_len, phone_lens, B * 4, hipMemcpyHostToDevice, s));
   GSV_HIP(hipMemcpyAsync(h->d_row_off, row_off.data(), B * 4, hipMemcpyHostToDevice, s));
   GSV_HIP(hipMemcpyAsync(h->d_ph_off, ph_off.data(), B * 4, hipMemcpyHostToDevice, s));
-  GSV_HIP(hipMemcpyAsync(h->d_kv_len, kvl.data(), B * 4, hipMemcpyHostToDevice, s));
-  GSV_HIP(hipMemcpyAsync(h->d_active, ones.data(), B * 4, hipMemcpyHostToDevice, s));
-  GSV_HIP(hipMemcpyAsync(h->d_step, zeros.data(), B * 4, hipMemcpyHostToDevice, s));
-  GSV_HIP(hipMemcpyAsync(h->d_n_active, &B, 4, hipMemcpyHostToDevice, s));
+  {
+    // row state [kv_len | active | step | n_active] is one block: one upload
+    const size_t mb = (size_t)h->max_batch;
+    std::vector<int> st(3 * mb + 4, 0);
+    for (int b = 0; b < B; ++b) { st[b] = kvl[b]; st[mb + b] = 1; }
+    st[3 * mb] = B;
+    GSV_HIP(hipMemcpyAsync(h->d_kv_len, st.data(), st.size() * 4, hipMemcpyHostToDevice, s));
+    GSV_HIP(hipStreamSynchronize(s));
+  }
   if (P > 0)
     GSV_HIP(hipMemcpy2DAsync(h->d_ytok, (size_t)h->ycap * 4, prompts, (size_t)P * 4, (size_t)P * 4, B, hipMemcpyDeviceToDevice, s));
   GSV_HIP(hipStreamSynchronize(s));  // host vectors above go out of scope
@@ -1484,6 +1494,8 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
   p.early_stop_num = sp->early_stop_num; p.eos_mask_steps = sp->eos_mask_steps; p.max_steps = sp->max_steps;
   p.noise_rows = noise ? noise_rows : 0; p.seed = sp->seed; p.noise = noise; p.out_tokens = out_tokens; p.out_len = out_len;
   p.P = h->P;
+  p.force = h->dbg_force; p.dump = h->dbg_dump; p.drawn = h->dbg_drawn;
+  h->dbg_force = nullptr; h->dbg_dump = nullptr; h->dbg_drawn = nullptr;
   GSV_HIP(hipMemcpyAsync(h->d_sp, &p, sizeof(p), hipMemcpyHostToDevice, s));
   GSV_HIP(hipStreamSynchronize(s));
   // budget: step 0 samples from the prefill's last position, every later step appends one K/V position, so the
@@ -1512,8 +1524,14 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
     }
     if (m.census == 1) {
       static const bool map_local = getenv("GSV_MEGA_GROUP_XCD") != nullptr;
-      GSV_HIP(hipMemsetAsync(m.hop, 0, m.hop_bytes, s));      // tags restart at 1 every call
+      GSV_HIP(hipMemsetAsync(m.hop, 0, m.hop_bytes, s));      // no tag survives a call (epochs are unique per launch as well: ep_base)
       GSV_HIP(hipMemsetAsync(m.err, 0, 64, s));
+      // the row state as step 0 left it: if the launch ends in a hand-off timeout the batch is re-run from here on the
+      // launch-per-phase path (the engine only appends K/V behind kv_len and token history behind P + step: restoring the
+      // counters makes both invisible again; ybuf, the first step's input, is read-only for the engine)
+      const size_t mb = (size_t)h->max_batch;
+      GSV_HIP(hipMemcpyAsync(m.snap, h->d_kv_len, (3 * mb + 4) * 4, hipMemcpyDeviceToDevice, s));
+      GSV_HIP(hipMemcpyAsync(m.snap + 3 * mb + 4, out_len, h->B * 4, hipMemcpyDeviceToDevice, s));
       MegaArgs a;
       memset(&a, 0, sizeof(a));
       a.wpack = (const h8*)m.wpack; a.lpack = (const h8*)m.lpack; a.fpack = m.fpack;
@@ -1529,6 +1547,7 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
       a.ring = m.ring;
       m.launch_gen = (m.launch_gen + 1) & 2047;
       a.ep_base = m.launch_gen << 20;                       // 1500 steps x 98 hops < 2^20
+      a.test_stall = h->dbg_stall; h->dbg_stall = 0;        // tests only (gsv_t2s_debug_stall): this launch loses one publish
       // measurement runs: GSV_MEGA_PROF=<file> dumps in-kernel shader-clock stamps of one (step, layer) for every wave
       const char* prof_path = getenv("GSV_MEGA_PROF");
       unsigned long long* d_prof = nullptr;
@@ -1545,11 +1564,24 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
       GSV_HIP(hipMemcpyAsync(m.h_err, m.err, 16, hipMemcpyDeviceToHost, s));
       GSV_HIP(hipMemcpyAsync(h->h_pinned, h->d_step, 4, hipMemcpyDeviceToHost, s));
       GSV_HIP(hipStreamSynchronize(s));
+      bool engine_ok = true;
       if (m.h_err[0] != 0u) {
-        set_error("t2s_decode: persistent engine hand-off timed out (epoch %u, workgroup %u, hop code %u); "
-                  "set GSV_T2S_NO_MEGA=1 to use the launch-per-phase step", m.h_err[1], m.h_err[2], m.h_err[3]);
-        return GSV_ERR_STATE;
+        // A hand-off timed out (a member was not running: another kernel held its CU, or a fault).  The request is not
+        // failed: the row state is restored to what step 0 left, the handle stops using the engine (census = 0: later calls
+        // take the launch-per-phase step, gsv_t2s_engine_stats reports it) and THIS batch is re-run below on that path.
+        // GSV_MEGA_STRICT=1 restores the old behaviour (GSV_ERR_STATE) for tests of the error path.
+        set_error("t2s_decode: persistent engine hand-off timed out (epoch %u, workgroup %u, hop code 0x%x); the handle now uses "
+                  "the launch-per-phase step (GSV_T2S_NO_MEGA=1 selects it from the start)", m.h_err[1], m.h_err[2], m.h_err[3]);
+        m.fallbacks += 1;
+        m.census = m.fallbacks >= 3 ? 0 : -1;     // a transient cause (a foreign kernel held a CU): census again at the next call; three strikes disable the engine
+        m.last_err[0] = m.h_err[1]; m.last_err[1] = m.h_err[2]; m.last_err[2] = m.h_err[3];
+        if (d_prof) (void)hipFree(d_prof);
+        if (getenv("GSV_MEGA_STRICT")) return GSV_ERR_STATE;
+        GSV_HIP(hipMemcpyAsync(h->d_kv_len, m.snap, (3 * mb + 4) * 4, hipMemcpyDeviceToDevice, s));
+        GSV_HIP(hipMemcpyAsync(out_len, m.snap + 3 * mb + 4, h->B * 4, hipMemcpyDeviceToDevice, s));
+        engine_ok = false;
       }
+      if (engine_ok) {
       (void)hipEventElapsedTime(&h->last_decode_ms, h->mega_ev[0], h->mega_ev[1]);
       if (d_prof) {
         std::vector<unsigned long long> hp(prof_n);
@@ -1574,6 +1606,7 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
       h->last_decode_mode = 1; h->last_decode_steps = budget - 1;
       if (steps_run) *steps_run = budget;
       return GSV_OK;
+      }   // engine_ok
     }
   }
   // steps >= 1 : captured once per batch size, replayed
@@ -1611,6 +1644,26 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
 int gsv_t2s_set_mega(gsv_t2s_t* h, int on) {
   GSV_REQUIRE(h, "t2s_set_mega: null handle");
   h->mega_on = on != 0;
+  return GSV_OK;
+}
+
+int gsv_t2s_set_debug(gsv_t2s_t* h, const int32_t* force_tokens, float* logits_dump, int32_t* drawn_dump) {
+  GSV_REQUIRE(h && h->finalized, "t2s_set_debug: handle not finalized");
+  h->dbg_force = force_tokens; h->dbg_dump = logits_dump; h->dbg_drawn = drawn_dump;
+  return GSV_OK;
+}
+
+int gsv_t2s_debug_stall(gsv_t2s_t* h, int member) {
+  GSV_REQUIRE(h && h->finalized && member >= 0 && member < 32, "t2s_debug_stall: bad argument");
+  h->dbg_stall = member + 1;
+  return GSV_OK;
+}
+
+int gsv_t2s_engine_stats(gsv_t2s_t* h, int* engine_available, int* fallbacks, unsigned* last_error3) {
+  GSV_REQUIRE(h && h->finalized, "t2s_engine_stats: handle not finalized");
+  if (engine_available) *engine_available = h->mega.ready && h->mega.census != 0 ? 1 : 0;
+  if (fallbacks) *fallbacks = h->mega.fallbacks;
+  if (last_error3) { last_error3[0] = h->mega.last_err[0]; last_error3[1] = h->mega.last_err[1]; last_error3[2] = h->mega.last_err[2]; }
   return GSV_OK;
 }
 

@@ -20,6 +20,9 @@ struct MegaState {        // owned by the t2s handle
   unsigned* err = nullptr;        // [4]: timeout word, epoch, block, code
   unsigned* h_err = nullptr;      // pinned host copy
   int census = -1;                // -1 not run, 0 failed (mega disabled), 1 all 256 workgroups co-resident
+  int* snap = nullptr;            // row state saved in front of a launch: [kv_len | active | step | n_active(4)][out_len]
+  unsigned last_err[3] = {0, 0, 0};   // epoch, workgroup, hop code of the last timeout
+  int fallbacks = 0;              // launches that ended in a hand-off timeout and were re-run on the launch path
   bool ready = false;
 };
 
@@ -39,6 +42,7 @@ struct MegaArgs {
   int map_shared;                 // 1: workgroups reading the same weight slice share an XCD (default), 0: group = XCD
   int ring;                       // hop buffer sets used round-robin over (step, layer); > 1 enables L2-shared payload reads
   unsigned ep_base;               // launch generation << 20: epochs never repeat between launches (stale cached lines cannot match)
+  int test_stall;                 // tests only (gsv_t2s_debug_stall): member test_stall - 1 of group 0 skips one publish; 0 = off
 };
 
 // shape gate: the persistent engine is specialised for the v1/v2 decoder

@@ -169,11 +169,15 @@ __device__ __forceinline__ lds_int* st_cbar(const Ctx&) { return (lds_int*)(unsi
 // Barrier among the 4 compute waves only (an s_barrier would also wait for the comm waves, which are busy issuing the next
 // layer's K/V loads during P1): an arrival counter in LDS; LDS operations of a wave complete in order, so the add is behind
 // the wave's earlier LDS writes.  `gen` counts arrivals expected so far (same in every compute wave).
+__device__ __noinline__ void mega_fail(gu32* err, int lane, unsigned epoch, unsigned code);
 __device__ __forceinline__ void compute_barrier(const Ctx& q, int& gen) {
   gen += 4;
   if (q.lane == 0) __hip_atomic_fetch_add(st_cbar(q), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   unsigned spins = 0;
   while (*(lds_vint*)st_cbar(q) < gen && !*st_abort(q) && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(0);
+  // a wave that gives up must not go on to reduce partial sums another wave has not written: like every other bounded spin
+  // of the engine it sets the abort flag and the error word (code 0x40), and the caller returns at its abort test
+  if (spins >= (1u << 24)) mega_fail(q.err, q.lane, (unsigned)gen, 0x40u);
   asm volatile("" ::: "memory");
 }
 
@@ -757,6 +761,15 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         if (sp.noise) nrow = sp.noise + ((size_t)step * sp.noise_rows + (sp.noise_rows > 1 ? b : 0)) * V;
         int smp, amx;
         sample_core<17>(x, Veff, sp.top_k, sp.top_p, sp.temperature, nrow, sp.seed, b, step, &smp, &amx);
+        if (sp.dump) {                                       // parity hooks (gsv_t2s_set_debug), null in production
+#pragma unroll
+          for (int i = 0; i < 17; ++i) {
+            const int v = q.lane + 64 * i;
+            if (v < V) sp.dump[((size_t)step * a.B + b) * V + v] = __uint_as_float(lv[i]);
+          }
+        }
+        if (sp.drawn && q.lane == 0) { int* dr = sp.drawn + ((size_t)step * a.B + b) * 2; dr[0] = smp; dr[1] = amx; }
+        if (sp.force) { smp = sp.force[(size_t)b * sp.max_steps + step]; amx = smp; }
         const bool fin = smp == EOS || amx == EOS;
         const bool early = (sp.early_stop_num != -1 && (step + 1) > sp.early_stop_num) || step >= sp.max_steps - 1;
         const int prev_len = sp.P + step;
@@ -924,7 +937,10 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         }
         // transposed through LDS (same wave): lane = row * 16 + column, so each row's 16 granules = one 128-B line
         // written whole by ONE store instruction (scattered 8-B write-through stores made every hop 2-3x slower)
-        if (q.lane < R * 16)
+        // test hook (gsv_t2s_debug_stall, tests only): that member of group 0 skips ONE publish, so that the group's
+        // bounded waits must end the launch with an error instead of hanging
+        const bool stall = a.test_stall && q.member == a.test_stall - 1 && q.group == 0 && s == 2 && l == 3;
+        if (q.lane < R * 16 && !stall)
           gstore(q.hop + HOP_C + (q.lane >> 4) * 512 + 16 * q.member + (q.lane & 15), ep0 + 4 * l + 3,
                  __float_as_uint(((const float*)(smem + L_STAGE))[q.lane]));
       }
@@ -1178,11 +1194,9 @@ int mega_census(hipStream_t s, unsigned* d_scratch, unsigned* h_pinned) {
 }
 
 int launch_t2s_mega(const MegaArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
-    attr_set = true;
-  }
+  // every launch: the attribute belongs to the (function, device) pair, and TTS.set_device may have moved the handle's owner
+  // to another GPU of the process since the last launch (mega_census does the same)
+  GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
   hipLaunchKernelGGL(t2s_mega_kernel, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
   GSV_HIP(hipGetLastError());
   return GSV_OK;

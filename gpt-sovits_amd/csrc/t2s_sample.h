@@ -22,6 +22,10 @@ struct StepParams {
   int* out_tokens;         // [B][max_steps]
   int* out_len;            // [B]
   int P;                   // prompt length (position offset of generated tokens)
+  // parity hooks (gsv_t2s_set_debug; null in production): teacher forcing and a per-step dump of the raw logits
+  const int* force;        // [B][max_steps]: the token taken at step s of row b instead of the sampled one
+  float* dump;             // [max_steps][B][V]: logits of every executed step, before the repetition penalty
+  int* drawn;              // [max_steps][B][2]: (token the sampler drew, argmax of the penalised logits) before any forcing
 };
 
 

@@ -105,7 +105,7 @@ class Text2SemanticDecoder:
     # ---- engine call ---------------------------------------------------------------
     def _run(self, x: Sequence[torch.Tensor], prompts: torch.Tensor, bert: Sequence[torch.Tensor], top_k, top_p,
              early_stop_num, temperature, repetition_penalty, eos_mask_steps, noise=None, seed=0,
-             max_steps: int = 1500):
+             max_steps: int = 1500, force_tokens=None, dump_logits=False):
         if not self._loaded:
             raise RuntimeError("load_state_dict() first")
         B = len(x)
@@ -165,6 +165,25 @@ class Text2SemanticDecoder:
                                          pr.data_ptr() if P > 0 else None, P, s),
                        "gsv_t2s_prefill")
             steps = C.c_int(0)
+            dump = None
+            if force_tokens is not None or dump_logits:
+                # parity hooks (tests): teacher forcing and the per-step logits of whichever decode path runs
+                ft = None
+                if force_tokens is not None:
+                    ft = torch.zeros(B, budget, dtype=torch.int32, device=dev)
+                    src = force_tokens.to(dev, torch.int32)
+                    n = min(budget, int(src.shape[1]))
+                    ft[:, :n] = src[:, :n]
+                drawn = None
+                if dump_logits:
+                    dump = torch.zeros(budget, B, self.vocab_size, dtype=torch.float32, device=dev)
+                    drawn = torch.full((budget, B, 2), -1, dtype=torch.int32, device=dev)
+                torch.cuda.current_stream(dev).synchronize()
+                _lib.check(l.gsv_t2s_set_debug(self._h, ft.data_ptr() if ft is not None else None,
+                                               dump.data_ptr() if dump is not None else None,
+                                               drawn.data_ptr() if drawn is not None else None), "gsv_t2s_set_debug")
+                self.last_drawn_dump = drawn
+            self.last_logits_dump = dump
             _lib.check(l.gsv_t2s_decode(self._h, C.byref(sp), noise_dev.data_ptr() if noise_dev is not None else None,
                                         noise_rows, out_tokens.data_ptr(), out_len.data_ptr(), C.byref(steps), s),
                        "gsv_t2s_decode")
@@ -208,7 +227,9 @@ class Text2SemanticDecoder:
                 nz = noise[:, lo:hi]
             y, i = self._run(x[lo:hi], prompts[lo:hi], bert_feature[lo:hi], top_k, top_p, early_stop_num, temperature,
                              repetition_penalty, eos_mask_steps=1, noise=nz, seed=kwargs.get("seed", 0),
-                             max_steps=kwargs.get("max_steps", 1500))
+                             max_steps=kwargs.get("max_steps", 1500),
+                             force_tokens=None if kwargs.get("force_tokens") is None else kwargs["force_tokens"][lo:hi],
+                             dump_logits=kwargs.get("dump_logits", False))
             ys[lo:hi] = y
             idxs[lo:hi] = i
         return ys, idxs
@@ -244,6 +265,17 @@ class Text2SemanticDecoder:
         """A/B switch: False makes later calls use the launch-per-phase decode step instead of the persistent engine
         (csrc/t2s_mega.hip; fp16, v1/v2 shape, batch <= 32)."""
         _lib.check(_lib.lib().gsv_t2s_set_mega(self._h, int(bool(on))), "gsv_t2s_set_mega")
+
+    def debug_stall(self, member: int):
+        """test hook: the next persistent launch loses one hand-off publish of `member` (group 0)"""
+        _lib.check(_lib.lib().gsv_t2s_debug_stall(self._h, int(member)), "gsv_t2s_debug_stall")
+
+    def engine_stats(self):
+        """(engine_available, fallbacks, (epoch, workgroup, hop code) of the last hand-off timeout): a persistent launch
+        that times out is re-run on the launch-per-phase step and the handle stops using the engine."""
+        av, fb, e3 = C.c_int(0), C.c_int(0), (C.c_uint * 3)()
+        _lib.check(_lib.lib().gsv_t2s_engine_stats(self._h, C.byref(av), C.byref(fb), e3), "gsv_t2s_engine_stats")
+        return bool(av.value), fb.value, tuple(e3)
 
     def decode_info(self):
         """(mode, device_ms, steps) of the last decode call: mode 1 = persistent engine, 0 = launch per phase."""

@@ -66,6 +66,9 @@ _SIGS = {
                                  C.POINTER(C.c_int), C.c_void_p]),
     "gsv_t2s_decode_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "gsv_t2s_set_mega": (C.c_int, [C.c_void_p, C.c_int]),
+    "gsv_t2s_engine_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint)]),
+    "gsv_t2s_set_debug": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsv_t2s_debug_stall": (C.c_int, [C.c_void_p, C.c_int]),
     "gsv_t2s_debug_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsv_t2s_time_step": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]),
     "gsv_t2s_debug_set_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

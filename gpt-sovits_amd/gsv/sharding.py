@@ -11,8 +11,13 @@ fragments, point to point (xGMI: one link per peer into rank 0, no ring, no all-
   batches are dealt round-robin.
 * Streaming (configs[4], reference `return_fragment`, TTS.py:1321): `run_stream` yields on rank 0 as soon as the next batch
   IN ORDER has arrived; rank 0 works on its own batches in between and only blocks on a receive when the queue is empty.
-* `run` (configs[1] / [2]) returns the whole job's audio in submission order.
-* A rank whose synthesis raises still sends its header (with an error flag) so that nobody waits for it; rank 0 re-raises.
+* `run` (configs[1] / [2]) returns the whole job's audio in submission order; every rank keeps its int16 results on its GPU
+  and sends ONE record to rank 0 over RCCL when its queue is empty (no send is ever in flight beside a decode engine).
+* Streamed fragments (`run_stream`) travel over a host-side gloo group: they are int16 on the host already, and an RCCL send
+  posted before rank 0's receive would keep a kernel resident on the sender's GPU while its persistent decode engine needs
+  every CU.
+* A rank whose synthesis raises still sends its record (with an error flag) so that nobody waits for it; rank 0 receives
+  every outstanding record -- also when its own batch failed -- and re-raises afterwards.
 
 One process per GPU, `torch.distributed` (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests).
 """
@@ -119,6 +124,7 @@ class ShardedSynthesizer:
             except Exception:
                 self.store = None
         self._job = 0
+        self._hg = None
         self.last_synth_s = 0.0
         self.last_owner: List[int] = []
 
@@ -178,21 +184,37 @@ class ShardedSynthesizer:
         return audio, list(frag_lens), err
 
     # ---- the job ---------------------------------------------------------------------------------------------------
+    def _host_group(self):
+        """process group for HOST-side point-to-point traffic (streamed fragments).  Under RCCL a posted send is a kernel
+        that stays resident on the sender's GPU until rank 0 posts the matching receive; the persistent AR decode engine
+        needs every CU, so a send left in flight while the next batch decodes can starve one of its workgroups
+        (ADVICE r2).  Streamed fragments are int16 on the host already, so they travel over a gloo group instead; the
+        job-level gather of `run` uses RCCL at a point where no engine is running."""
+        if self._hg is None:
+            if not self.on or self.world == 1 or dist.get_backend(self.group) == "gloo":
+                self._hg = self.group
+            else:
+                self._hg = dist.new_group(backend="gloo")          # collective: every rank constructs it at the same point
+        return self._hg
+
     def run_stream(self, segments: Optional[List[dict]], batch_size: int = 32, ship_bert: bool = True
                    ) -> Iterator[Tuple[List[int], List[np.ndarray]]]:
         """rank 0 passes all segments (the others None).  On rank 0 yields (segment indices of the batch, their int16 fragments)
-        batch by batch in the order of `make_batches`; on the other ranks yields nothing but must be iterated to the end."""
-        dev = self.device
+        batch by batch in the order of `make_batches`; on the other ranks yields nothing but must be iterated to the end.
+        A failure anywhere (rank 0's own batch included) is raised on rank 0 AFTER every outstanding batch of the other
+        ranks has been received, so that no rank is left waiting in a send."""
         self._job += 1
         job = self._job
         self.last_synth_s = 0.0
+        hg = self._host_group() if self.world > 1 else None
         segments, batch_size = self._broadcast_segments(segments, batch_size, ship_bert)
         batches = make_batches([len(s["norm_text"]) for s in segments], batch_size)
         nb = len(batches)
-        done = {}                       # rank 0: batch index -> (audio host array, frag_lens) of its own batches
+        done = {}                       # rank 0: batch index -> (audio host array, frag_lens) or None (failed)
         taken: List[int] = []
         pending = []                    # other ranks: in-flight sends (buffers must outlive them)
         self.last_owner = [-1] * nb
+        failure: List[Optional[BaseException]] = [None]
 
         def work_one() -> bool:
             k = self._next_batch(job, nb, taken)
@@ -200,16 +222,18 @@ class ShardedSynthesizer:
                 return False
             taken.append(k)
             audio, frag_lens, err = self._synth_batch([segments[i] for i in batches[k]])
+            host = to_host(audio) if audio.is_cuda else audio.numpy()
             if self.rank == 0:
                 if err:
-                    raise self._last_exc
-                done[k] = (to_host(audio) if audio.is_cuda else audio.numpy(), frag_lens)
+                    done[k] = None
+                    failure[0] = failure[0] or self._last_exc
+                else:
+                    done[k] = (host, frag_lens)
             else:
-                # header: [batch, error, n_samples, frag lens...] then the samples as raw bytes (neither RCCL nor gloo has int16)
-                hdr = torch.tensor([k, err, audio.numel()] + frag_lens, dtype=torch.int64, device=dev)
-                pay = audio.to(dev).contiguous().view(torch.uint8) if audio.numel() else torch.zeros(2, dtype=torch.uint8, device=dev)
-                pending.append((hdr, pay, dist.isend(hdr, 0, group=self.group, tag=2 * k),
-                                dist.isend(pay, 0, group=self.group, tag=2 * k + 1)))
+                # header: [batch, error, n_samples, frag lens...] then the samples as raw bytes (gloo has no int16)
+                hdr = torch.tensor([k, err, int(host.size)] + frag_lens, dtype=torch.int64)
+                pay = torch.from_numpy(np.ascontiguousarray(host)).view(torch.uint8) if host.size else torch.zeros(2, dtype=torch.uint8)
+                pending.append((hdr, pay, dist.isend(hdr, 0, group=hg, tag=2 * k), dist.isend(pay, 0, group=hg, tag=2 * k + 1)))
             return True
 
         if self.rank != 0:
@@ -222,33 +246,46 @@ class ShardedSynthesizer:
         more = True
         for k in range(nb):
             while k not in done:
-                if more:
+                if more and failure[0] is None:
                     more = work_one()
+                    continue
+                if self.world == 1 or (self.store is None and k % self.world == 0):
+                    done[k] = None          # rank 0's own batch that will not be synthesised any more (a failure came first)
                     continue
                 owner = self._owner(job, k)
                 assert owner != 0, "a batch claimed by rank 0 is always in `done`"
-                hdr = torch.zeros(3 + len(batches[k]), dtype=torch.int64, device=dev)
-                dist.recv(hdr, owner, group=self.group, tag=2 * k)
+                hdr = torch.zeros(3 + len(batches[k]), dtype=torch.int64)
+                dist.recv(hdr, owner, group=hg, tag=2 * k)
                 h = hdr.tolist()
-                pay = torch.zeros(max(2 * h[2], 2), dtype=torch.uint8, device=dev)
-                dist.recv(pay, owner, group=self.group, tag=2 * k + 1)
-                if h[1]:
-                    raise RuntimeError(f"rank {owner} failed while synthesising batch {k}")
-                a = pay[: 2 * h[2]].view(torch.int16)
-                done[k] = (to_host(a) if a.is_cuda else a.numpy().copy(), [int(v) for v in h[3:]])
+                pay = torch.zeros(max(2 * h[2], 2), dtype=torch.uint8)
+                dist.recv(pay, owner, group=hg, tag=2 * k + 1)
                 self.last_owner[k] = owner
+                if h[1]:
+                    failure[0] = failure[0] or RuntimeError(f"rank {owner} failed while synthesising batch {k}")
+                    done[k] = None
+                else:
+                    done[k] = (pay[: 2 * h[2]].view(torch.int16).numpy().copy(), [int(v) for v in h[3:]])
             if self.last_owner[k] < 0:
                 self.last_owner[k] = 0
-            audio, frag_lens = done.pop(k)
+            item = done.pop(k)
+            if item is None or failure[0] is not None:
+                continue                    # after a failure: keep receiving (drain), stop emitting
+            audio, frag_lens = item
             frags, o = [], 0
             for ln in frag_lens:
                 frags.append(audio[o:o + ln])
                 o += ln
             yield list(batches[k]), frags
+        if failure[0] is not None:
+            raise failure[0]
 
     def run(self, segments: Optional[List[dict]], batch_size: Optional[int] = None, ship_bert: bool = True) -> Optional[np.ndarray]:
         """whole job: rank 0 returns the int16 audio of all fragments in submission order, the other ranks None.
-        `batch_size` None = one batch per rank (configs[1]'s weak-scaling step: 32 utterances per GPU)."""
+        `batch_size` None = one batch per rank (configs[1]'s weak-scaling step: 32 utterances per GPU).
+
+        Every rank synthesises the batches it claims and keeps the int16 result on its GPU; when its queue is empty it sends
+        ONE record to rank 0 over the device group (RCCL point to point over xGMI: sizes, then fragment table, then samples),
+        i.e. the gather happens when no decode engine is running on the sender and rank 0 has finished its own work."""
         if batch_size is None:
             n = len(segments) if self.rank == 0 else 0
             if self.world > 1:
@@ -256,12 +293,74 @@ class ShardedSynthesizer:
                 dist.broadcast(t, 0, group=self.group)
                 n = int(t.item())
             batch_size = max(1, -(-n // self.world))
-        n_total = len(segments) if self.rank == 0 else 0
-        out: List[Optional[np.ndarray]] = [None] * n_total
-        for idxs, frags in self.run_stream(segments, batch_size, ship_bert):
-            for i, f in zip(idxs, frags):
-                out[i] = f
+        if self.world == 1:
+            n_total = len(segments)
+            out: List[Optional[np.ndarray]] = [None] * n_total
+            for idxs, frags in self.run_stream(segments, batch_size, ship_bert):
+                for i, f in zip(idxs, frags):
+                    out[i] = f
+            keep = [f for f in out if f is not None]
+            return np.concatenate(keep) if keep else np.zeros(0, dtype=np.int16)
+        dev = self.device
+        self._job += 1
+        job = self._job
+        self.last_synth_s = 0.0
+        segments, batch_size = self._broadcast_segments(segments, batch_size, ship_bert)
+        batches = make_batches([len(s["norm_text"]) for s in segments], batch_size)
+        nb = len(batches)
+        self.last_owner = [-1] * nb
+        taken: List[int] = []
+        mine = []                           # (batch, audio tensor, frag_lens)
+        err, exc = 0, None
+        while True:
+            k = self._next_batch(job, nb, taken)
+            if k is None:
+                break
+            taken.append(k)
+            audio, frag_lens, e = self._synth_batch([segments[i] for i in batches[k]])
+            if e:
+                err, exc = 1, self._last_exc
+                break                       # stop claiming: with the work queue the other ranks take what is left
+            mine.append((k, audio, frag_lens))
+        table = [v for k, _a, fl in mine for v in [k, len(fl)] + fl]
         if self.rank != 0:
+            pay = torch.cat([a.to(dev).reshape(-1) for _k, a, _f in mine]) if mine else torch.zeros(1, dtype=torch.int16, device=dev)
+            sizes = torch.tensor([len(table), int(pay.numel()), err], dtype=torch.int64, device=dev)
+            dist.send(sizes, 0, group=self.group)
+            dist.send(torch.tensor(table + [0], dtype=torch.int64, device=dev), 0, group=self.group)
+            dist.send(pay.view(torch.uint8), 0, group=self.group)
             return None
+        out = [None] * len(segments)
+        failed = [f"rank 0: {exc!r}"] if err else []
+        for k, a, fl in mine:
+            self.last_owner[k] = 0
+            host = to_host(a) if a.is_cuda else a.numpy()
+            o = 0
+            for i, ln in zip(batches[k], fl):
+                out[i] = host[o:o + ln]
+                o += ln
+        for r in range(1, self.world):
+            sizes = torch.zeros(3, dtype=torch.int64, device=dev)
+            dist.recv(sizes, r, group=self.group)
+            nt, ns, rerr = (int(v) for v in sizes.tolist())
+            tab = torch.zeros(nt + 1, dtype=torch.int64, device=dev)
+            dist.recv(tab, r, group=self.group)
+            pay = torch.zeros(2 * max(ns, 1), dtype=torch.uint8, device=dev)
+            dist.recv(pay, r, group=self.group)
+            if rerr:
+                failed.append(f"rank {r}")
+            host = to_host(pay.view(torch.int16))
+            t, p, o = tab.tolist(), 0, 0
+            while p < nt:
+                k, nf = t[p], t[p + 1]
+                self.last_owner[k] = r
+                for i, ln in zip(batches[k], t[p + 2:p + 2 + nf]):
+                    out[i] = host[o:o + ln]
+                    o += ln
+                p += 2 + nf
+        if failed:
+            if exc is not None:
+                raise exc
+            raise RuntimeError(f"sharded synthesis failed on {', '.join(failed)}")
         keep = [f for f in out if f is not None]
         return np.concatenate(keep) if keep else np.zeros(0, dtype=np.int16)

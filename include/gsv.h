@@ -98,7 +98,24 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
 int gsv_t2s_decode_info(gsv_t2s_t* h, int* mode, float* device_ms, int* steps);
 /* A/B switch inside one process: on = 0 makes later decode calls of this handle use the launch-per-phase step */
 int gsv_t2s_set_mega(gsv_t2s_t* h, int on);
-/* test hooks: logits of the last completed step [dev] fp32 [B][vocab] (launch-per-phase path and step 0 only) */
+/* Robustness report.  A persistent launch whose hand-off timed out (a member workgroup was not running: its CU was held
+ * by another kernel) does not fail the request: the row state is restored, the batch is re-run on the launch-per-phase
+ * step and the handle stops using the engine.  engine_available = 0 after that (or when the engine was never built),
+ * fallbacks = launches that ended that way, last_error3 [host] = {epoch, workgroup, hop code} of the last timeout. */
+int gsv_t2s_engine_stats(gsv_t2s_t* h, int* engine_available, int* fallbacks, unsigned* last_error3);
+/* Parity hooks for the NEXT gsv_t2s_decode call only (both decode paths, every dtype; not a reference feature -- SURVEY.md
+ * section 7 asks for a teacher-forced logit comparison of the fp16 engine):
+ *   force_tokens [dev] int32 [B][max_steps] or NULL: step s of row b continues with force_tokens[b][s] instead of the
+ *     token it sampled (EOS / early-stop bookkeeping then sees the forced token);
+ *   logits_dump [dev] fp32 [max_steps][B][vocab] or NULL: raw logits (before the repetition penalty) of every step run;
+ *   drawn_dump [dev] int32 [max_steps][B][2] or NULL: (token the sampler drew, argmax of the penalised logits) of every
+ *     step run, recorded BEFORE forcing -- lets a test replay the engine's sampling (noise indexing, counter RNG, repetition
+ *     bookkeeping) step by step with gsv_op_sample / the oracle on the dumped logits. */
+int gsv_t2s_set_debug(gsv_t2s_t* h, const int32_t* force_tokens, float* logits_dump, int32_t* drawn_dump);
+/* test hook: member `member` (0..31) of row group 0 skips ONE hand-off publish in the next persistent launch, which must then
+ * end through its bounded waits (never hang), be re-run on the launch-per-phase step and be counted by gsv_t2s_engine_stats */
+int gsv_t2s_debug_stall(gsv_t2s_t* h, int member);
+/* test hook: logits of each row's last sampled step [dev] fp32 [B][vocab] (either decode path) */
 int gsv_t2s_debug_logits(gsv_t2s_t* h, float* out, gsv_stream_t stream);
 /* per-kernel timing of the decode step: average device time (ms) of one step over `iters`
  * replays at the current cache length, and of the decode-attention kernel alone. */

@@ -122,14 +122,24 @@ def _gloo_worker(rank, world, port, q, mode):
                 time.sleep(0.4)                                     # uneven work: the queue must hand the rest to the idle ranks
             if mode == "fail" and rank == world - 1:
                 raise RuntimeError("engine failure on the last rank")
+            if mode in ("fail0_stream", "fail0_run") and rank == 0:
+                time.sleep(0.2)                                     # the other rank has batches in flight when rank 0 fails
+                raise RuntimeError("engine failure on rank 0")
+            if mode == "many" and rank == 1:
+                time.sleep(0.05)
             return _stub_synth(segments)
         sh = sharding.ShardedSynthesizer(synth, torch.device("cpu"), dynamic=mode not in ("static", "fail"))   # static dealing: the failing rank is sure to own a batch
-        if mode in ("stream", "slow_rank1"):
+        if mode == "many" and rank == 0:
+            segs = [{"phones": [i % 50 + 1] * 2, "bert_features": None, "norm_text": "x" * (i + 1)} for i in range(24)]
+        if mode in ("stream", "slow_rank1", "fail0_stream", "many"):
             order, flat = [], []
-            for idxs, frags in sh.run_stream(segs, batch_size=2):
-                order.append(idxs)
-                flat.append([f.tolist() for f in frags])
-            q.put((rank, {"order": order, "flat": flat, "calls": calls, "owner": list(sh.last_owner)}))
+            try:
+                for idxs, frags in sh.run_stream(segs, batch_size=2):
+                    order.append(idxs)
+                    flat.append([f.tolist() for f in frags])
+                q.put((rank, {"order": order, "flat": flat, "calls": calls, "owner": list(sh.last_owner)}))
+            except RuntimeError as e:
+                q.put((rank, {"error": str(e), "order": order, "calls": calls}))
         else:
             try:
                 out = sh.run(segs, batch_size=2 if mode != "weak" else None)
@@ -189,6 +199,25 @@ def test_sharded_bert_features_are_shipped_and_failures_propagate():
     assert out[50:80] == [103] * 30 and out[:40] == [1] * 40           # the zh segment arrived WITH its features
     res = _run_gloo(3, "fail", 63)
     assert "error" in res[0] and "failed" in res[0]["error"]           # rank 0 raises instead of waiting for ever
+
+
+@pytest.mark.parametrize("mode", ["fail0_stream", "fail0_run"])
+def test_rank0_failure_drains_the_other_ranks_before_raising(mode):
+    """rank 0's OWN batch fails while rank 1 has results in flight: rank 0 must receive them before it re-raises, otherwise
+    rank 1 blocks in its send; every process exits with code 0 (checked by _run_gloo)."""
+    res = _run_gloo(2, mode, {"fail0_stream": 71, "fail0_run": 83}[mode])
+    assert "error" in res[0] and "rank 0" in res[0]["error"]
+    assert "error" not in res[1]                                        # rank 1 finished its sends and left normally
+    assert sum(res[1]["calls"]) >= 1
+
+
+def test_streaming_many_batches_per_rank():
+    """12 batches over 2 ranks (more than 2 per rank): all emitted in make_batches order, every batch once."""
+    res = _run_gloo(2, "many", 97)
+    r0 = res[0]
+    assert r0["order"] == [[2 * i, 2 * i + 1] for i in range(12)]
+    assert len(res[0]["calls"]) + len(res[1]["calls"]) == 12 and len(res[1]["calls"]) >= 1
+    assert sorted(set(r0["owner"])) == [0, 1]
 
 
 def os_getpid():
