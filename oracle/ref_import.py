@@ -80,3 +80,46 @@ def synthesizer_cls():
     setup()
     from module.models import SynthesizerTrn  # noqa
     return SynthesizerTrn
+
+
+def tts_module():
+    """The reference's `TTS_infer_pack.TTS` module (pipeline glue: to_batch, recovery_order, audio_postprocess,
+    using_vocoder_synthesis*, sola_algorithm; TTS.py:842-973, 1377-1635).  Its module-scope imports (TTS.py:10-37) name
+    packages that are absent here and that none of the pinned methods touch: ffmpeg, peft, pytorch_lightning (through
+    AR.models.t2s_lightning_module), tools.audio_sr, tools.i18n, sv, TextPreprocessor's G2P stack; they are replaced by empty
+    stubs, like torchmetrics / x_transformers above.  The methods are then called UNBOUND on a namespace that carries the
+    reference's own stage classes (oracle/gen_golden_tts_glue.py)."""
+    import transformers  # noqa: F401  (imported before the torchaudio stub exists: its availability probe needs a real spec or nothing)
+    setup()
+    import torch
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return None
+
+    class _I18n:
+        def __init__(self, language=None):
+            pass
+
+        def __call__(self, key):
+            return key
+
+    sys.modules["torchaudio"].transforms.Resample = _Dummy
+    for name, attrs in (("ffmpeg", {}), ("pytorch_lightning", {"LightningModule": torch.nn.Module}),
+                        ("peft", {"LoraConfig": _Dummy, "get_peft_model": _Dummy}), ("sv", {"SV": _Dummy}),
+                        ("tools.audio_sr", {"AP_BWE": _Dummy}),
+                        ("tools.i18n.i18n", {"I18nAuto": _I18n, "scan_language_list": lambda: []}),
+                        ("TTS_infer_pack.TextPreprocessor", {"TextPreprocessor": _Dummy})):
+        if name not in sys.modules:
+            parts = name.split(".")
+            for i in range(1, len(parts)):
+                pk = ".".join(parts[:i])
+                if pk not in sys.modules and pk not in ("TTS_infer_pack",):
+                    m = _stub(pk)
+                    m.__path__ = []
+            _stub(name, **attrs)
+    import TTS_infer_pack.TTS as ref_tts  # noqa
+    return ref_tts

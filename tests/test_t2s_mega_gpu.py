@@ -158,7 +158,9 @@ def test_eos_finishes_ragged_rows_every_batch_size(B):
     """rows finish by EOS at different steps (the EOS row of ar_predict_layer is made a slightly amplified copy of a
     token that row 0 emits early, so EOS wins the argmax whenever that token would), ragged text lengths, every batch
     size: finishing bookkeeping (idx, lengths, token ranges) is self-consistent and, for rows whose ids agree with the
-    launch path, identical to it; rows of a group keep running after a neighbour has finished."""
+    launch path, identical to it; a row may differ from the launch path only from a step on at which the launch path's
+    own top-2 margin is a near-tie (< 0.1; both paths carry <= 3e-2 of fp16 noise); rows of a group keep running after a
+    neighbour has finished."""
     from gsv import synthetic as S
     cfg, sd = _v2(seed=3, suppress_eos=True)
     utt = S.make_utterances(B)
@@ -195,17 +197,35 @@ def test_eos_finishes_ragged_rows_every_batch_size(B):
     ya, ia = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
     assert eng.decode_info()[0] == 1
     eng.set_mega(False)
-    yb, ib = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
-    same = 0
-    for a, b, na, nb in zip(ya, yb, ia, ib):
+    yb, ib = eng.infer_panel_batch_infer(xs, None, prompts, berts, dump_logits=True, **kw)
+    Lb = eng.last_logits_dump.cpu()            # launch path's raw logits [steps][B][V]
+    eng.set_mega(True)
+    from oracle.t2s_oracle import apply_repetition_penalty
+    same, near_ties = 0, []
+    for r, (a, b, na, nb) in enumerate(zip(ya, yb, ia, ib)):
         assert a.shape[0] == P + na and 0 <= na <= 48
         assert na == 0 or int(a[P:].max().item()) < 1024
-        if a.tolist() == b.tolist():
+        if a.tolist() == b.tolist() and na == nb:
             same += 1
-            assert na == nb
-    print(f"[mega] B={B}: {same}/{B} rows identical to the launch path; finish steps engine {ia} launch path {ib}")
+            continue
+        # The two fp16 paths may part ways only at a NEAR-TIE.  The case builds one on purpose: the EOS row of the predict layer
+        # is 1.002 x the trigger token's row, so whenever the trigger token leads, EOS leads it by 0.2 % of the logit (~0.02 at
+        # |logit| ~ 10) -- inside the fp16 noise band of either path (<= 3e-2 each, test_one_pass_logits...).  That is what made
+        # B = 2 finish at [6, 7] vs [6, 6] in profiles/r02_parity_log.txt.  Asserted here: at the first step where the rows
+        # differ (a different token, or one path finishing), the launch path's penalised top-2 margin is below 0.1.
+        ga, gb = a.tolist()[P:], b.tolist()[P:]
+        dstep = _common_prefix(ga, gb)
+        lg = Lb[dstep, r].clone().unsqueeze(0)
+        if dstep < 1:
+            lg = lg[:, :-1]
+        pen = apply_repetition_penalty(lg, b[:P + dstep].cpu().view(1, -1), 1.35)[0]
+        top2 = torch.topk(pen, 2).values
+        margin = float(top2[0] - top2[1])
+        near_ties.append((r, dstep, round(margin, 4)))
+        assert margin < 0.1, f"row {r} leaves the launch path at step {dstep} where its top-2 margin is {margin:.3f} (not a near-tie)"
+    print(f"[mega] B={B}: {same}/{B} rows identical to the launch path; finish steps engine {ia} launch path {ib}; "
+          f"divergences (row, step, launch-path top-2 margin): {near_ties}")
     assert min(ia) < 48 and (B < 9 or len(set(ia)) > 1), f"the case must contain EOS finishes at different steps: {ia} (expected about {expect_first})"
-    assert same >= (B + 1) // 2
 
 
 def test_direct_abi_refuses_budget_beyond_arena():

@@ -199,3 +199,34 @@ def test_fp32_folded_decode_at_benchmark_length_vs_oracle():
     err = (wav - ref).abs().max().item()
     print(f"[parity] fp32 SoVITS folded decode, 400 frames: max-abs error {err:.2e} (waveform rms {ref.pow(2).mean().sqrt():.3f})")
     assert err <= 1e-4
+
+
+def test_fp16_folded_decode_at_benchmark_length_vs_oracle():
+    """The production dtype at the benchmark's SoVITS shape: two 100-token utterances folded into the time
+    axis (400 frames, 256 000 samples).  At this length the decode runs the fp16-only kernels the bench spends its time in --
+    `conv_wide_f16` (128 channels, T = 32 000 >= 16 384), `conv_pair_f16` (32 / 16 channels), `conv_narrow_f16` (64 channels),
+    `flash_rel96_f16` (enc_p attention) -- composed end to end, against the fp32 CPU oracle (pinned on the reference class):
+    waveform max-abs <= 2e-2 and relative rms <= 3 %, the fp16 bar of DESIGN.md section 2."""
+    from gsv import synthetic as S
+    from gsv.module.models import SynthesizerTrn
+    from oracle.vits_oracle import VitsOracle
+    cfg = S.VITS_V2_CONFIG
+    sd = S.make_vits_state_dict(cfg, seed=0)
+    d = cfg["data"]
+    v = SynthesizerTrn(d["filter_length"] // 2 + 1, cfg["train"]["segment_size"] // d["hop_length"], n_speakers=d["n_speakers"],
+                       version="v2", device="cuda:0", dtype=torch.float16, n_symbols=cfg.get("n_symbols"), **cfg["model"])
+    v.load_state_dict(sd)
+    codes = torch.from_numpy(S.hash_ints("bench_codes", 200, 1024, 0)).view(1, 1, -1)
+    text = torch.from_numpy(S.hash_ints("bench_text", 80, 732, 0)).view(1, -1)
+    refer = S.make_refer_spec()
+    noise = S.hash_normal("bench_vits_noise", (cfg["model"]["inter_channels"], 400), 0)
+    torch.set_num_threads(8)
+    ref = VitsOracle(sd, cfg).decode(codes, text, [refer], noise=noise)
+    wav = v.decode(codes.to("cuda:0"), text.to("cuda:0"), [refer.to("cuda:0")], noise=noise).float().cpu()
+    assert wav.shape == ref.shape == (1, 1, 400 * 640)
+    assert torch.isfinite(wav).all()
+    err = (wav - ref).abs().max().item()
+    rel = ((wav - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print(f"[parity] fp16 SoVITS folded decode, 400 frames: max-abs error {err:.2e}, relative rms {rel * 100:.2f} % "
+          f"(waveform rms {ref.pow(2).mean().sqrt():.3f})")
+    assert err <= 2e-2 and rel <= 0.03
