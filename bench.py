@@ -198,6 +198,45 @@ def extra_cold_prompt(tts, dev):
             "what": "set_ref_audio: 8 s reference (host WAV read + resample, HuBERT-base 12 x 768, extract_latent, spectrogram)"}
 
 
+def extra_total_1024(sh, make_segs, B, tok_count):
+    """BASELINE configs[2] at its stated size on ONE GPU: 1024 utterances in batches of B through the work queue
+    (the per-GPU share of the 8-GPU job is 128; the 1 -> 8 curve itself is the driver's SCALE record)."""
+    _utt, segs = make_segs(1024)
+    tok_count[0] = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = sh.run(segs, batch_size=B)
+    dt = time.perf_counter() - t0
+    audio_s = tok_count[0] * 0.04
+    return {"workload": f"BASELINE configs[2] on one GPU: 1024 utterances, {1024 // B} batches of {B} from the work queue, fp16",
+            "value": round(audio_s / dt, 1), "unit": "audio_s/s", "ms": round(1e3 * dt, 1), "utterances": 1024,
+            "samples": int(out.size)}
+
+
+def extra_long_form(sh, make_segs, B, tok_count):
+    """BASELINE configs[4] on ONE GPU: a 1400-word text = 140 sentences of 10 words, streamed in reading order (batches of B in
+    submission order, `wire.streaming_generator` framing): throughput and the time to the first audible fragment."""
+    from gsv import wire
+    _utt, segs = make_segs(140)
+    tok_count[0] = 0
+    first = [None]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+
+    def gen():
+        for _idx, frags in sh.run_stream(segs, batch_size=B, bucket=False):
+            if first[0] is None:
+                first[0] = time.perf_counter() - t0
+            yield 32000, np.concatenate(frags)
+
+    nbytes = sum(len(c) for c in wire.streaming_generator(gen(), "wav"))
+    dt = time.perf_counter() - t0
+    audio_s = tok_count[0] * 0.04
+    return {"workload": f"BASELINE configs[4] on one GPU: 140 sentences (1400 words) streamed in reading order, batches of {B}, wav chunks",
+            "value": round(audio_s / dt, 1), "unit": "audio_s/s", "ms": round(1e3 * dt, 1),
+            "time_to_first_fragment_ms": round(1e3 * first[0], 1), "bytes": nbytes}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -394,7 +433,9 @@ def main():
                                      "unfused_bytes": gen_bytes, "frac_hbm": round(gen_bytes / (vt_gen * 1e-3) / 8e12, 4)}
         log(f"gpu: {res['value']} audio_s/s, {res['ms_per_step']} ms/step; roofline {roof['achieved']} GB/s")
         if not args.no_extras and world == 1 and args.total_utterances == 0 and not args.fp32:
-            log("extras: fp32 value, v3 record, cold prompt ...")
+            log("extras: configs[2] / [4] at full size on this GPU, fp32 value, v3 record, cold prompt ...")
+            res["total_1024"] = extra_total_1024(sh, make_segments, B, tok_count)
+            res["long_form"] = extra_long_form(sh, make_segments, B, tok_count)
             res["cold_prompt"] = extra_cold_prompt(tts, dev)
             tts = None
             sh = None

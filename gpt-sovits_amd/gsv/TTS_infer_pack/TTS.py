@@ -738,6 +738,12 @@ class TTS:
             split_bucket = False
         if speed_factor != 1.0:
             split_bucket = False
+        elif getattr(self.configs, "use_vocoder", False) and parallel_infer:
+            split_bucket = False           # v3 / v4 parallel runs are never bucketed (reference TTS.py:1060-1062)
+        if inputs.get("super_sampling", False):
+            # reference TTS.py:1040, 1408-1419: AP_BWE super-sampling, a separate model that is out of scope (DESIGN.md
+            # section 7) -- refused, never silently ignored
+            raise NotImplementedError("super_sampling (AP_BWE audio super-resolution) is not part of this engine")
         try:
             if self.t2s_model is None or self.vits_model is None:
                 raise RuntimeError("init_t2s_weights / init_vits_weights first")

@@ -1,0 +1,112 @@
+"""GPU: BASELINE configs[2] and configs[4] at their STATED size on one GPU (VERDICT r2 missing 2): 1024 utterances through
+the work queue in batches of 32, and a 1400-word text (140 sentences of 10 words) streamed in reading order.  World size 1
+here; the multi-rank exchange of the same code is covered by the gloo tests (tests/test_host_logic.py), and the 1 -> 8 GPU
+curve is the driver's (SCALE_rNN.json)."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from gsv import synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOK, B = 100, 32
+GAP = int(32000 * 0.3)
+FRAG = TOK * 2 * 640 + GAP            # 4.0 s of audio + the 0.3 s fragment interval
+
+
+@pytest.fixture(scope="module")
+def pipeline():
+    from gsv.TTS_infer_pack.TTS import TTS
+    t2s_cfg = {k: dict(v) for k, v in S.T2S_V2_CONFIG.items()}
+    t2s_cfg["data"]["max_sec"] = TOK / 50.0
+    tts = TTS({"device": DEV, "is_half": True, "version": "v2", "max_batch": B, "max_seq": 80 + 100 + TOK + 16})
+    tts.init_t2s_weights(state={"weight": S.make_t2s_state_dict(S.T2S_V2_CONFIG, seed=0, suppress_eos=True), "config": t2s_cfg})
+    tts.init_vits_weights(state={"weight": S.make_vits_state_dict(S.VITS_V2_CONFIG, seed=0), "config": dict(S.VITS_V2_CONFIG)})
+    utt = S.make_utterances(1)
+    tts.set_prompt_cache(utt["prompt_semantic"], [S.make_refer_spec().to(DEV)], phones=utt["prompt_phones"],
+                         bert_features=torch.zeros(1024, len(utt["prompt_phones"])), norm_text="x" * 40)
+    params = dict(batch_size=B, top_k=1, top_p=1.0, temperature=1.0, repetition_penalty=1.35, seed=0, split_bucket=True,
+                  parallel_infer=True, fragment_interval=0.3)
+    calls = []
+
+    def synth(segments):
+        calls.append(time.perf_counter())
+        out = None
+        for sr, audio in tts.run(dict(params, segments=segments)):
+            out = audio
+        return out, list(tts.last_fragment_lengths)
+
+    return tts, synth, calls
+
+
+def _segments(n):
+    utt = S.make_utterances(n)
+    # text lengths vary so that the length-sorted batches are NOT the submission order
+    return [{"phones": it["phones"], "bert_features": torch.zeros(1024, len(it["phones"])), "norm_text": "x" * (30 + (7 * i) % 21)}
+            for i, it in enumerate(utt["items"])]
+
+
+def test_config2_1024_utterances_in_batches_of_32(pipeline):
+    """BASELINE configs[2] on one GPU: 1024 utterances -> 32 length-sorted batches of 32 from the work queue -> every
+    fragment 4.0 s + gap, submission order restored, two spot-checked batches equal to a direct TTS.run of their segments."""
+    from gsv import sharding
+    tts, synth, calls = pipeline
+    segs = _segments(1024)
+    sh = sharding.ShardedSynthesizer(synth, torch.device(DEV))
+    sh.run(segs[:64], batch_size=B)                       # warm-up (kernel load, arenas)
+    del calls[:]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    whole = sh.run(segs, batch_size=B)
+    dt = time.perf_counter() - t0
+    assert len(calls) == 32
+    assert whole.dtype == np.int16 and whole.size == 1024 * FRAG
+    frags = whole.reshape(1024, FRAG)
+    assert not frags[:, TOK * 2 * 640:].any(), "every fragment ends with the silence gap"
+    assert (np.abs(frags[:, : TOK * 2 * 640]).max(1) > 0).all(), "no fragment is silent"
+    assert tts.t2s_model.decode_info()[0] == 1 and tts.t2s_model.engine_stats()[1] == 0
+    batches = sharding.make_batches([len(s["norm_text"]) for s in segs], B)
+    assert batches[0] != list(range(32)), "the case must shuffle the submission order"
+    for k in (3, 29):                                     # spot check: the same segments through a direct call
+        ref, lens = synth([segs[i] for i in batches[k]])
+        assert lens == [FRAG] * 32
+        for j, i in enumerate(batches[k]):
+            assert np.array_equal(frags[i], ref[j * FRAG:(j + 1) * FRAG]), f"batch {k}, utterance {i}: not the audio of that utterance"
+    audio_s = 1024 * TOK * 0.04
+    print(f"[configs2] 1024 utterances (32 batches of 32) on one GPU: {dt * 1e3:.0f} ms = {audio_s / dt:.0f} audio-s/s")
+
+
+def test_config4_long_form_streams_in_reading_order(pipeline):
+    """BASELINE configs[4] on one GPU: 140 sentences (1400 words) -> batches in SUBMISSION order (bucketing off, as the
+    reference forces for streamed fragments, TTS.py:1050-1054) -> `wire.streaming_generator` frames them as one wav header +
+    raw chunks; the first fragment is out before the last batch starts."""
+    from gsv import sharding, wire
+    tts, synth, calls = pipeline
+    segs = _segments(140)
+    sh = sharding.ShardedSynthesizer(synth, torch.device(DEV))
+    del calls[:]
+    order, first_at = [], None
+    t0 = time.perf_counter()
+
+    def gen():
+        nonlocal first_at
+        for idxs, frags in sh.run_stream(segs, batch_size=B, bucket=False):
+            if first_at is None:
+                first_at = time.perf_counter()
+            order.extend(idxs)
+            yield 32000, np.concatenate(frags)
+
+    chunks = list(wire.streaming_generator(gen(), "wav"))
+    dt = time.perf_counter() - t0
+    assert order == list(range(140)), "fragments leave in reading order"
+    assert len(calls) == 5 and first_at < calls[-1], "the first fragment is emitted before the last batch starts"
+    assert chunks[0][:4] == b"RIFF" and len(chunks[0]) == 44 and len(chunks) == 1 + 5
+    body = np.frombuffer(b"".join(chunks[1:]), dtype=np.int16)
+    assert body.size == 140 * FRAG
+    whole = sh.run(segs, batch_size=B)                    # bucketed one-shot job: same utterances, different batch mates
+    assert whole.size == body.size
+    print(f"[configs4] 140 sentences streamed on one GPU: {dt * 1e3:.0f} ms total = {140 * TOK * 0.04 / dt:.0f} audio-s/s, first "
+          f"fragment after {(first_at - t0) * 1e3:.0f} ms")

@@ -59,6 +59,24 @@ def test_recovery_order():
         tts.audio_postprocess(audio, 32000, index, 1.0, True, fragment_interval=0.0001)
 
 
+def test_to_batch_and_recovery_order_match_the_reference_methods():
+    """TTS.to_batch / TTS.recovery_order against fixtures written by the REFERENCE's own methods (TTS.py:842-973, called
+    unbound by oracle/gen_golden_tts_glue.py): bucket composition and order, per-batch max_len, prompt-prefixed phones."""
+    from conftest import load_golden
+    from oracle import glue_cases as G
+    g = load_golden("tts_glue_host")
+    tts = _tts_cpu()
+    for ci, (lens, bs, thr, sb) in enumerate(G.TO_BATCH_CASES):
+        data, prompt_data = G.to_batch_data(lens)
+        batches, index = tts.to_batch(data, prompt_data, batch_size=bs, threshold=thr, split_bucket=sb)
+        assert [i for b in index for i in b] == g[f"tb{ci}_index"].tolist(), f"case {ci}: order"
+        assert [len(b) for b in index] == g[f"tb{ci}_sizes"].tolist(), f"case {ci}: bucket sizes"
+        assert [int(b["max_len"]) for b in batches] == g[f"tb{ci}_max_len"].tolist()
+        assert torch.cat([b["all_phones_len"] for b in batches]).tolist() == g[f"tb{ci}_all_len"].tolist()
+        assert torch.cat([p for b in batches for p in b["all_phones"]]).tolist() == g[f"tb{ci}_all_phones"].tolist()
+        assert tts.recovery_order([[str(i) for i in b] for b in index], index) == [str(i) for i in range(len(lens))]
+
+
 def test_deal_contiguous_batches_and_wire_format_roundtrip():
     lens = [5, 1, 9, 3, 7, 2, 8]
     shares = sharding.deal_contiguous(lens, 3)

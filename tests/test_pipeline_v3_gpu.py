@@ -195,3 +195,68 @@ def test_lora_checkpoint_is_merged_into_the_base_model():
     assert torch.equal(lora_out, want) and (lora_out - base_out).abs().max() > 1e-3
     with pytest.raises(FileExistsError):
         tts.init_vits_weights(state={"weight": lw, "config": vcfg, "lora_rank": 4})
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# against fixtures written by the REFERENCE's own TTS methods (oracle/gen_golden_tts_glue.py): H17 is pinned
+# ---------------------------------------------------------------------------------------------------------------------
+def _build_glue(version):
+    from gsv.TTS_infer_pack.TTS import TTS
+    from oracle import glue_cases as G
+    tcfg = S.small_t2s_config(n_layer=2, dim=128, head=4, vocab=1025, phoneme_vocab=732)
+    tsd = S.make_t2s_state_dict(tcfg, seed=11, suppress_eos=True)
+    vcfg, vsd, dit, ocfg, osd, kind = G.models(version)
+    vcfg = dict(vcfg, dit={k: v for k, v in dit.items() if k != "mel_dim"})
+    tts = TTS({"device": DEV, "is_half": False, "version": version, "max_batch": 4, "max_seq": 256})
+    tts.init_t2s_weights(state={"weight": tsd, "config": tcfg})
+    tts.init_vits_weights(state={"weight": vsd, "config": vcfg})
+    tts.init_vocoder(state={"weight": osd, "config": dict(ocfg, **G.VC)})
+    refer, psem, pph, ref_mel = G.prompt()
+    tts.set_prompt_cache(psem, [refer.to(DEV)], phones=pph, bert_features=torch.zeros(1024, 6), norm_text="xxxxxx", ref_mel=ref_mel)
+    return tts
+
+
+@pytest.mark.parametrize("version", ["v3", "v4"])
+def test_v3_glue_matches_fixtures_of_the_reference_methods(version):
+    """TTS.using_vocoder_synthesis and ..._batched_infer (HIP engines, fp32) == what the reference's own methods returned
+    over the reference's own stage classes: single fragment in 3 prompted chunks, and the batched variant (overlapping
+    chunks -> one batched CFM -> vocoder -> SOLA -> split) with equal fragment lengths (= equal SOLA offsets)."""
+    from conftest import load_golden
+    from oracle import glue_cases as G
+    g = load_golden(f"tts_glue_{version}")
+    tts = _build_glue(version)
+    sem, ph = G.single_inputs()
+    wav = tts.using_vocoder_synthesis(sem.to(DEV), ph.to(DEV), speed=1.0, sample_steps=3, noise_fn=G.noise_fn).float().cpu().numpy()
+    assert wav.shape == g["single"].shape
+    err = np.abs(wav - g["single"]).max()
+    print(f"[glue] {version} single fragment vs the reference method: max-abs {err:.2e}")
+    assert err <= 5e-3
+    for case in ("ragged", "exact"):
+        idx, sems, phs = G.batched_inputs(case)
+        out = tts.using_vocoder_synthesis_batched_infer(idx, [s.to(DEV) for s in sems], [p.to(DEV) for p in phs], speed=1.0,
+                                                        sample_steps=2, noise_fn=G.noise_fn)
+        assert [int(o.numel()) for o in out] == g[f"batched_{case}_lens"].tolist()
+        err = np.abs(torch.cat([o.float().cpu() for o in out]).numpy() - g[f"batched_{case}"]).max()
+        print(f"[glue] {version} batched {case} vs the reference method: max-abs {err:.2e}")
+        assert err <= 5e-3
+
+
+def test_sola_and_postprocess_kernels_match_fixtures_of_the_reference_methods():
+    """gsv_sola vs TTS.sola_algorithm and gsv_postprocess vs TTS.audio_postprocess (peak division in the fragment dtype,
+    silence gap, recovery order, x 32768 -> int16), both as the reference's own methods computed them."""
+    from conftest import load_golden
+    from gsv.TTS_infer_pack.TTS import TTS
+    from oracle import glue_cases as G
+    g = load_golden("tts_glue_host")
+    tts = TTS({"device": DEV, "is_half": False, "version": "v2"})
+    for ci, (n, length, ov) in enumerate(G.SOLA_CASES):
+        out = tts.sola_algorithm([f.to(DEV) for f in G.sola_fragments(n, length, ov)], ov).cpu().numpy()
+        assert out.shape == g[f"sola{ci}"].shape and np.abs(out - g[f"sola{ci}"]).max() <= 1e-5
+    for name, dtype in (("f32", torch.float32), ("f16", torch.float16)):
+        t = TTS({"device": DEV, "is_half": dtype == torch.float16, "version": "v2"})
+        for sb in (True, False):
+            audio, bil = G.postprocess_inputs(dtype)
+            sr, a16 = t.audio_postprocess([[f.to(DEV) for f in row] for row in audio], 32000, bil, 1.0, sb, 0.3)
+            want = g[f"post_{name}_{'bucket' if sb else 'flat'}"]
+            assert sr == 32000 and a16.dtype == np.int16 and a16.shape == want.shape
+            assert np.array_equal(a16, want), f"{name} split_bucket={sb}: {int((a16 != want).sum())} samples differ"
