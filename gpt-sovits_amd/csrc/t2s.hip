@@ -1539,7 +1539,8 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
       a.kv_len = h->d_kv_len; a.active = h->d_active; a.step_ctr = h->d_step; a.n_active = h->d_n_active;
       a.ytok = h->d_ytok; a.ycap = h->ycap; a.sp = h->d_sp; a.e_audio = h->e_audio; a.pe = h->pe; a.alpha_a = h->alpha_a;
       a.ybuf = h->ybuf; a.logits_out = h->logits; a.hop = m.hop; a.err = m.err; a.B = h->B; a.L = h->cfg.n_layer; a.V = h->cfg.vocab;
-      a.nsteps = budget - 1; a.map_shared = map_local ? 0 : 1;
+      static const int map_mode = getenv("GSV_MEGA_MAP") ? atoi(getenv("GSV_MEGA_MAP")) : 2;   // 2: roles by the XCD a workgroup runs on, 1: by blockIdx % 8
+      a.nsteps = budget - 1; a.map_shared = map_local ? 0 : map_mode;
       // bits 0-3: hops (A, B, C, D) that poll one granule per line first; bits 8-12: 16ths of the lines that may still be
       // missing when the full passes start
       static const int hint_mask = getenv("GSV_MEGA_HINT") ? atoi(getenv("GSV_MEGA_HINT")) : (15 | (2 << 8) | (6 << 13));   // bits 13-15: poll every 2^n-th payload line (6: one line per row)   // bit 4 (two polls in flight): 3 % slower; bit 5 (payload through L2, needs GSV_MEGA_RING > 1): no gain

@@ -1072,7 +1072,30 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   c.smem = smem;
   const int tid = threadIdx.x;
   c.lane = tid & 63; c.wave = __builtin_amdgcn_readfirstlane(tid >> 6); c.comm = c.wave < 4; c.cw = c.wave & 3; c.tid_c = tid - 256;
-  if (a.map_shared) { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; c.member = xcd * 4 + (slot >> 3); c.group = slot & 7; }
+  if (a.map_shared == 2) {
+    // Roles dealt by the XCD a workgroup actually RUNS on (HW_REG_XCC_ID) and its arrival order there: the 8 workgroups that
+    // stream the same weight slice (one per row group) share an L2 whatever the dispatcher did.  blockIdx % 8 is only a label
+    // of which blocks share an XCD under strict round-robin placement; when a CU is still busy at launch the dispatcher
+    // deviates from it and a slice is then pulled into several L2s (the ~6 % slower of the two modes seen run to run).
+    // Speed only: any assignment of the 256 (group, member) roles is correct.  32 workgroups of this footprint fit an XCD
+    // (one per CU); a 33rd ticket means the device is not what the census assumed: error exit, the host falls back.
+    if (tid == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      xcc &= 7u;
+      const unsigned t = __hip_atomic_fetch_add((gu32*)a.err + 8 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ((volatile int*)smem)[0] = (int)xcc;
+      ((volatile int*)smem)[1] = (int)t;
+    }
+    __syncthreads();
+    const int xcd = ((volatile int*)smem)[0], t = ((volatile int*)smem)[1];
+    __syncthreads();
+    if (t >= 32) {
+      if (tid == 0) { __hip_atomic_store((gu32*)a.err + 3, 0x50u, RLX_AGENT); __hip_atomic_store((gu32*)a.err, 1u, RLX_AGENT); }
+      return;
+    }
+    c.member = xcd * 4 + (t >> 3); c.group = t & 7;
+  } else if (a.map_shared) { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; c.member = xcd * 4 + (slot >> 3); c.group = slot & 7; }
   else { c.group = blockIdx.x & 7; c.member = blockIdx.x >> 3; }
   c.head = c.member >> 1; c.half = c.member & 1;
   c.R = a.B > c.group ? (a.B - c.group + MG_GROUPS - 1) / MG_GROUPS : 0;
