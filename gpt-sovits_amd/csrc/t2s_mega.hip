@@ -148,6 +148,7 @@ struct Ctx {
   int hint_miss16;              // hint phase ends when at most this many 16ths of the polled lines are still missing
   int hint_pipe;                // two hint polls in flight (GSV_MEGA_HINT bit 4)
   int hint_stride;              // poll every n-th payload line (1, 2, 4, 8)
+  int hint_one;                 // one polling wave per workgroup (wave 0 polls for all rows, LDS word to the others)
   unsigned long long* prof;     // this wave's 32 stamp slots or null
   bool prof_on;
 };
@@ -330,6 +331,29 @@ template <> __device__ __forceinline__ void wide_loads<8>(const gu64* p0, u4v (&
 template <int NQ>
 __device__ __forceinline__ bool sweep_wide(const Ctx& c, gu64* g, unsigned epoch, u4v (&q)[NQ], unsigned code, bool hint) {
   constexpr int NLINES = NQ * 8;                       // 16 granules per 128-byte line
+  if (hint && c.hint_one) {
+    // ONE polling wave per workgroup (GSV_MEGA_HINT bit 6): wave 0 polls the hint granule of every row of the group (lane r ->
+    // row r, one request per poll instead of one per wave) and tells the other sweepers through an LDS word; they spin on LDS
+    lds_vint* flag = (lds_vint*)(unsigned)L_ST + 15;
+    if (c.cw == 0) {
+      const gu64* gh = g + (NLINES - 1) * 16 + 15;       // this wave sweeps row 0: g is row 0's base
+      for (unsigned spins = 0;; ++spins) {
+        const bool miss = c.lane < c.R && (unsigned)(gload(const_cast<gu64*>(gh) + (size_t)c.lane * (NQ * 128)) >> 32) != epoch;
+        if (!__ballot(miss)) break;
+        if (spins > SPIN_MAX || *st_abort(c) || (spins & 1023u) == 1023u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
+          mega_fail(c.err, c.lane, epoch, code | 0x100u);
+          return false;
+        }
+        if (spins < 8) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
+      }
+      *flag = (int)epoch;
+    } else {
+      for (unsigned spins = 0; *flag != (int)epoch; ++spins) {
+        if (spins > (SPIN_MAX << 4) || *st_abort(c)) { mega_fail(c.err, c.lane, epoch, code | 0x200u); return false; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  } else
   if (hint) {                                          // as in sweep2: the last granule of every line first
     for (unsigned spins = 0;; ++spins) {
       // every hint_stride-th line only (GSV_MEGA_HINT bits 13-14): fewer requests per poll, a weaker hint
@@ -1111,6 +1135,7 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   c.hint_miss16 = (a.hint_mask >> 8) & 31;
   c.hint_pipe = (a.hint_mask >> 4) & 1;
   c.hint_stride = 1 << ((a.hint_mask >> 13) & 7);
+  c.hint_one = (a.hint_mask >> 6) & 1;
   const int lane = c.lane, R = c.R;
   const StepParams sp = *a.sp;
 

@@ -343,17 +343,28 @@ class ShardedSynthesizer:
             for i, ln in zip(batches[k], fl):
                 out[i] = host[o:o + ln]
                 o += ln
+        # every rank's record lands in ONE device buffer (the receives are stream-ordered, nothing waits on the host in
+        # between) and crosses PCIe as one page-locked copy: 7 x 8 MB of int16 at N = 8
+        recs = []
         for r in range(1, self.world):
             sizes = torch.zeros(3, dtype=torch.int64, device=dev)
             dist.recv(sizes, r, group=self.group)
             nt, ns, rerr = (int(v) for v in sizes.tolist())
             tab = torch.zeros(nt + 1, dtype=torch.int64, device=dev)
             dist.recv(tab, r, group=self.group)
-            pay = torch.zeros(2 * max(ns, 1), dtype=torch.uint8, device=dev)
-            dist.recv(pay, r, group=self.group)
+            recs.append((r, nt, max(ns, 1), rerr, tab))
+        big = torch.zeros(2 * sum(rec[2] for rec in recs), dtype=torch.uint8, device=dev)
+        o8 = 0
+        for r, nt, ns, rerr, tab in recs:
+            dist.recv(big[o8:o8 + 2 * ns], r, group=self.group)
+            o8 += 2 * ns
+        host_all = to_host(big.view(torch.int16)) if recs else np.zeros(0, dtype=np.int16)
+        base = 0
+        for r, nt, ns, rerr, tab in recs:
             if rerr:
                 failed.append(f"rank {r}")
-            host = to_host(pay.view(torch.int16))
+            host = host_all[base:base + ns]
+            base += ns
             t, p, o = tab.tolist(), 0, 0
             while p < nt:
                 k, nf = t[p], t[p + 1]
