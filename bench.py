@@ -213,6 +213,42 @@ def extra_total_1024(sh, make_segs, B, tok_count):
             "samples": int(out.size)}
 
 
+def extra_total_1024_b128(dev, TOK, params, prompt_args, make_segs):
+    """the same 1024 utterances in 8 batches of 128: the AR decode of a batch is ONE persistent launch in which every row group
+    serves four quads of rows (csrc/t2s_mega.hip, t2s_mega_kernel<true>); SoVITS folds the 128 utterances into one decode as
+    the reference does for a batch (TTS.py:1266-1273)"""
+    from gsv.sharding import ShardedSynthesizer
+    B = 128
+    tts = build_tts(dev, TOK, B)
+    tts.set_prompt_cache(*prompt_args[0], **prompt_args[1])
+    toks = [0]
+    ar_ms = []
+
+    def synth(segments):
+        out = None
+        for _sr, audio in tts.run(dict(params, batch_size=B, segments=segments)):
+            out = audio
+        toks[0] += tts.last_generated_tokens
+        ar_ms.append(tts.t2s_model.decode_info())
+        return out, list(tts.last_fragment_lengths)
+
+    sh = ShardedSynthesizer(synth, dev)
+    _utt, segs = make_segs(1024)
+    sh.run(segs[:256], batch_size=B)                      # warm-up: kernel load, arenas, host buffers
+    toks[0] = 0
+    del ar_ms[:]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = sh.run(segs, batch_size=B)
+    dt = time.perf_counter() - t0
+    mode, ms, steps = ar_ms[-1]
+    return {"workload": "BASELINE configs[2] on one GPU: 1024 utterances, 8 batches of 128 (one persistent AR launch per batch), fp16",
+            "value": round(toks[0] * 0.04 / dt, 1), "unit": "audio_s/s", "ms": round(1e3 * dt, 1), "utterances": 1024,
+            "samples": int(out.size), "ar_decode_mode": "persistent engine" if mode == 1 else "launch per phase",
+            "ar_step_ms": round(ms / steps, 4) if mode == 1 and steps else None,
+            "stage_ms_last_batch": {"ar_t34": round(1e3 * tts.last_timing[2], 1), "sovits_decode_t45": round(1e3 * tts.last_timing[3], 1)}}
+
+
 def extra_long_form(sh, make_segs, B, tok_count):
     """BASELINE configs[4] on ONE GPU: a 1400-word text = 140 sentences of 10 words, streamed in reading order (batches of B in
     submission order, `wire.streaming_generator` framing): throughput and the time to the first audible fragment."""
@@ -439,6 +475,8 @@ def main():
             res["cold_prompt"] = extra_cold_prompt(tts, dev)
             tts = None
             sh = None
+            gc.collect(); torch.cuda.empty_cache()
+            res["total_1024_b128"] = extra_total_1024_b128(dev, TOK, params, prompt_args, make_segments)
             gc.collect(); torch.cuda.empty_cache()
             res["fp32"] = extra_fp32(dev, B, TOK, params, segs_all[:B], prompt_args)
             gc.collect(); torch.cuda.empty_cache()

@@ -47,7 +47,7 @@ struct MegaArgs {
 
 // shape gate: the persistent engine is specialised for the v1/v2 decoder
 bool mega_shape_ok(int dim, int n_head, int ffn, int vocab);
-constexpr int MEGA_MAX_B = 32;
+constexpr int MEGA_MAX_B = 128;       // 8 row groups x 4 quads x 4 rows; B <= 32 is the single-quad kernel
 
 // host: pack the fp32 staged weights of one layer into the engine's load order (fp16)
 void mega_pack_layer(const float* qkv_w, const float* out_w, const float* w1, const float* w2, _Float16* dst);

@@ -31,6 +31,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "t2s_mega.h"
 
 namespace gsv {
@@ -48,7 +50,8 @@ typedef unsigned long long u64;
 namespace {
 
 constexpr int MG_GROUPS = 8, MG_MEMBERS = 32, MG_NWG = MG_GROUPS * MG_MEMBERS, MG_THREADS = 512;
-constexpr int RMAX = 4;                       // rows per group (B <= 32)
+constexpr int RMAX = 4;                       // rows of a group served together: one QUAD (B <= 32: the group's only quad)
+constexpr int QMAX = 4;                       // quads per group (B <= 128): phase by phase one quad after the other, see t2s_mega_kernel
 constexpr int D = 512, NH = 16, HD = 32, FF = 2048;
 constexpr int XS_LD = 528, HS_LD = 2064;      // LDS row strides in halfs (rows 32 B apart mod 256 B: conflict-free b128 reads)
 constexpr int KV_CAP = 320;                   // cached positions per own row held in the LDS image (rest: global loads)
@@ -69,11 +72,12 @@ constexpr int HOP_B = HOP_ST + 64;                  // [RMAX][256] half pairs (a
 constexpr int HOP_C = HOP_B + RMAX * 256;           // [RMAX][512] fp32 y1
 constexpr int HOP_D = HOP_C + RMAX * 512;           // [RMAX][1024] half pairs (FFN hidden)
 constexpr int HOP_E = HOP_D + RMAX * 1024;          // [RMAX][VPAD] fp32 logits
-constexpr int HOP_GROUP = HOP_E + RMAX * VPAD;
+constexpr int HOP_GROUP = HOP_E + RMAX * VPAD;     // one quad's buffers
+constexpr int HOP_GROUP_ALL = QMAX * HOP_GROUP;    // a group's buffers: quad after quad
 
 // LDS carve (bytes); everything dynamic so the base stays 16-byte aligned
-constexpr int L_Y = 0;                                        // fp32 [RMAX][512]   (unused rows stay zero)
-constexpr int L_XRES = L_Y + RMAX * 512 * 4;                  // fp32 [RMAX][512]   LayerNorm output (residual operand)
+constexpr int L_RS = 0;                                       // f4 [2][QMAX][64]   residual operands kept per quad (multi-quad launches)
+constexpr int L_XRES = L_RS + 2 * QMAX * 64 * 16;             // fp32 [RMAX][512]   LayerNorm output (residual operand)
 constexpr int L_XS = L_XRES + RMAX * 512 * 4;                 // half [RMAX][XS_LD] LayerNorm output (MFMA operand)
 constexpr int L_AT = L_XS + RMAX * XS_LD * 2;                 // half [RMAX][XS_LD] attention output of all heads
 constexpr int L_HS = L_AT + RMAX * XS_LD * 2;                 // half [RMAX][HS_LD] FFN hidden
@@ -81,8 +85,9 @@ constexpr int L_RED = L_HS + RMAX * HS_LD * 2;                // f4 [24][64] spl
 constexpr int L_QKV = L_RED + 24 * 64 * 16;                   // half [2][3][32] q,k,v of the own rows
 constexpr int L_ATT = L_QKV + 2 * 3 * 32 * 2;                 // float [8] m + [8 waves][4 rows of 16 lanes][36] acc,l partials
 constexpr int L_STAGE = L_ATT + 32 + 8 * 4 * 36 * 4;          // 4 x 1 KB: per-wave transposition buffers of the publishers
-constexpr int L_ST = L_STAGE + 4 * 1024;                      // int: active[RMAX], kvlen[RMAX], step[RMAX], abort, any_active
-constexpr int L_SEEN = L_ST + 64;                             // bytes [VPAD]
+constexpr int L_ST = L_STAGE + 4 * 1024;                      // int: active[QMAX * RMAX], kvlen[..], step[..], abort, -, barrier counter, flag
+constexpr int ST_N = QMAX * RMAX;                             // rows of a group
+constexpr int L_SEEN = L_ST + (3 * ST_N + 16) * 4;            // bytes [VPAD]
 constexpr int L_KV = (L_SEEN + VPAD + 63) & ~63;              // [2 rows][K|V][KV_CAP][64 B]
 constexpr int L_TOTAL = L_KV + 2 * 2 * KV_CAP * 64;
 static_assert(L_TOTAL <= 160 * 1024, "LDS budget");
@@ -139,7 +144,8 @@ struct Ctx {
   unsigned char* smem;
   int lane, wave, cw, tid_c;
   bool comm;
-  int group, member, head, half, R;
+  int group, member, head, half, R;   // R = rows of the CURRENT quad
+  int qd, Rtot;                       // current quad; rows of the group (all quads)
   gu64* hop;                    // this group's hop buffers of the current (step, layer) ring slot
   gu64* hop_base;               // slot 0
   int ring, nlayer;             // ring slots; virtual layers per step (L + 1: the tail is one)
@@ -161,11 +167,12 @@ struct Ctx {
 // barrier (seen in the ISA; the dynamic LDS segment starts at LDS address 0: there is no static LDS in this kernel).
 typedef __attribute__((address_space(3))) int lds_int;
 typedef volatile __attribute__((address_space(3))) int lds_vint;
-__device__ __forceinline__ lds_int* st_active(const Ctx&) { return (lds_int*)(unsigned)L_ST; }
-__device__ __forceinline__ lds_int* st_kvlen(const Ctx&) { return (lds_int*)(unsigned)L_ST + RMAX; }
-__device__ __forceinline__ lds_int* st_step(const Ctx&) { return (lds_int*)(unsigned)L_ST + 2 * RMAX; }
-__device__ __forceinline__ lds_vint* st_abort(const Ctx&) { return (lds_vint*)(unsigned)L_ST + 3 * RMAX; }
-__device__ __forceinline__ lds_int* st_cbar(const Ctx&) { return (lds_int*)(unsigned)L_ST + 3 * RMAX + 2; }
+// the accessors return the CURRENT quad's four entries (local row lr = 4 * quad + r)
+__device__ __forceinline__ lds_int* st_active(const Ctx& c) { return (lds_int*)(unsigned)L_ST + RMAX * c.qd; }
+__device__ __forceinline__ lds_int* st_kvlen(const Ctx& c) { return (lds_int*)(unsigned)L_ST + ST_N + RMAX * c.qd; }
+__device__ __forceinline__ lds_int* st_step(const Ctx& c) { return (lds_int*)(unsigned)L_ST + 2 * ST_N + RMAX * c.qd; }
+__device__ __forceinline__ lds_vint* st_abort(const Ctx&) { return (lds_vint*)(unsigned)L_ST + 3 * ST_N; }
+__device__ __forceinline__ lds_int* st_cbar(const Ctx&) { return (lds_int*)(unsigned)L_ST + 3 * ST_N + 2; }
 
 // Barrier among the 4 compute waves only (an s_barrier would also wait for the comm waves, which are busy issuing the next
 // layer's K/V loads during P1): an arrival counter in LDS; LDS operations of a wave complete in order, so the add is behind
@@ -185,7 +192,7 @@ __device__ __forceinline__ void compute_barrier(const Ctx& q, int& gen) {
 // by value: a `const Ctx&` parameter of a non-inlined function forces the whole Ctx into scratch memory, re-stored at the
 // start of every phase (30 scratch instructions in the hot loops, seen in the ISA)
 __device__ __noinline__ void mega_fail(gu32* err, int lane, unsigned epoch, unsigned code) {
-  *(lds_vint*)((lds_vint*)(unsigned)L_ST + 3 * RMAX) = 1;               // st_abort
+  *(lds_vint*)((lds_vint*)(unsigned)L_ST + 3 * ST_N) = 1;               // st_abort
   if (lane == 0) {
     __hip_atomic_store(err + 1, epoch, RLX_AGENT);
     __hip_atomic_store(err + 2, (unsigned)blockIdx.x, RLX_AGENT);
@@ -334,7 +341,7 @@ __device__ __forceinline__ bool sweep_wide(const Ctx& c, gu64* g, unsigned epoch
   if (hint && c.hint_one) {
     // ONE polling wave per workgroup (GSV_MEGA_HINT bit 6): wave 0 polls the hint granule of every row of the group (lane r ->
     // row r, one request per poll instead of one per wave) and tells the other sweepers through an LDS word; they spin on LDS
-    lds_vint* flag = (lds_vint*)(unsigned)L_ST + 15;
+    lds_vint* flag = (lds_vint*)(unsigned)L_ST + 3 * ST_N + 3;
     if (c.cw == 0) {
       const gu64* gh = g + (NLINES - 1) * 16 + 15;       // this wave sweeps row 0: g is row 0's base
       for (unsigned spins = 0;; ++spins) {
@@ -460,14 +467,21 @@ __device__ __forceinline__ void relaunder(Ctx& q) {
 // stays resident on the memory side, 14 MB of rotating lines do not), and the L2-shared payload read gains nothing on top.
 // Default: one set, sc1 payload reads.
 __device__ __forceinline__ gu64* hop_slot(const Ctx& c, int s, int l) {
-  return c.hop_base + (size_t)((unsigned)(s * c.nlayer + l) % (unsigned)c.ring) * ((size_t)MG_GROUPS * HOP_GROUP);
+  return c.hop_base + (size_t)((unsigned)(s * c.nlayer + l) % (unsigned)c.ring) * ((size_t)MG_GROUPS * HOP_GROUP_ALL) + (size_t)c.qd * HOP_GROUP;
 }
 
 __device__ __forceinline__ bool group_done(const Ctx& c) {
   int any = 0;
-  for (int r = 0; r < c.R; ++r) any |= st_active(c)[r];
+  for (int r = 0; r < c.Rtot; ++r) any |= ((lds_int*)(unsigned)L_ST)[r];      // every quad's rows
   return !any;
 }
+// make quad `qd` the current one: its rows, its state entries (through c.qd), and -- via hop_slot -- its hop buffers
+__device__ __forceinline__ void set_quad(Ctx& c, int qd) {
+  c.qd = __builtin_amdgcn_readfirstlane(qd);
+  c.R = __builtin_amdgcn_readfirstlane(min(RMAX, c.Rtot - RMAX * qd));
+}
+// batch row of the current quad's local row r
+__device__ __forceinline__ int batch_row(const Ctx& c, int r) { return c.group + MG_GROUPS * (RMAX * c.qd + r); }
 
 // Attention of the member's own rows (H4: softmax(q K^T / sqrt(32)) V over the cached keys + this step's key): row ro is
 // served by NW waves, its keys dealt to them in 16-key groups, 4 lanes per key (8 dims each).  Two passes over the
@@ -534,7 +548,7 @@ __device__ __forceinline__ void attention_part(const MegaArgs& a, const Ctx& q, 
     for (int i = 0; i < 8; ++i) acc[i] += p * (float)v8[i];
   }
   if (n_old > KV_CAP) {                                // long rows: the tail comes straight from HBM (online update)
-    const _Float16* kvb = a.kv + ((size_t)(q.group + MG_GROUPS * r) * NH + q.head) * (size_t)a.smax * HD + part * 8;
+    const _Float16* kvb = a.kv + ((size_t)batch_row(q, r) * NH + q.head) * (size_t)a.smax * HD + part * 8;
     const _Float16* kg_ = kvb + (size_t)(l * 2 + 0) * a.kv_layer_stride;
     const _Float16* vg_ = kvb + (size_t)(l * 2 + 1) * a.kv_layer_stride;
     for (int j0 = KV_CAP + hq * 16; j0 < n_old; j0 += 16 * NW) {
@@ -591,19 +605,20 @@ struct KvStage { h8 r[KV_T]; };
 // The row state is read ONCE per call: as written first, every one of the 20 loads sat behind two dependent LDS reads (active,
 // kv_len), a readfirstlane and ~40 scalar address instructions -- the ISA showed the "burst" trickling out over ~3.5 us.
 struct KvRows { int nki[2]; };
-__device__ __forceinline__ KvRows kv_rows(const Ctx& q, int extra) {
+__device__ __forceinline__ KvRows kv_rows(const Ctx& q, int qd, int extra) {     // of quad qd (the one the image is staged for)
   KvRows k;
+  const int Rq = min(RMAX, q.Rtot - RMAX * qd);
 #pragma unroll
   for (int ro = 0; ro < 2; ++ro) {
-    const int r = 2 * ro + q.half;                   // < RMAX: the state arrays hold RMAX entries
-    const int act = st_active(q)[r], len = st_kvlen(q)[r];
-    k.nki[ro] = __builtin_amdgcn_readfirstlane(r < q.R && act ? (min(len + extra, KV_CAP) + 15) >> 4 : 0);
+    const int r = 2 * ro + q.half;                   // < RMAX
+    const int act = ((lds_int*)(unsigned)L_ST)[RMAX * qd + r], len = ((lds_int*)(unsigned)L_ST + ST_N)[RMAX * qd + r];
+    k.nki[ro] = __builtin_amdgcn_readfirstlane(r < Rq && act ? (min(len + extra, KV_CAP) + 15) >> 4 : 0);
   }
   return k;
 }
 
-__device__ __forceinline__ void kv_stage_load(const MegaArgs& a, const Ctx& q, int layer, int extra, KvStage& st) {
-  const KvRows k = kv_rows(q, extra);
+__device__ __forceinline__ void kv_stage_load(const MegaArgs& a, const Ctx& q, int layer, int qd, int extra, KvStage& st) {
+  const KvRows k = kv_rows(q, qd, extra);
   const h8* base[2][2];
 #pragma unroll
   for (int ro = 0; ro < 2; ++ro)
@@ -611,7 +626,7 @@ __device__ __forceinline__ void kv_stage_load(const MegaArgs& a, const Ctx& q, i
     for (int which = 0; which < 2; ++which)
       // the arena is allocated to smax positions per (row, head): a partly valid KiB reads allocated memory
       base[ro][which] = (const h8*)(a.kv + (size_t)(layer * 2 + which) * a.kv_layer_stride +
-                                    ((size_t)(q.group + MG_GROUPS * (2 * ro + q.half)) * NH + q.head) * (size_t)a.smax * HD) + q.lane;
+                                    ((size_t)(q.group + MG_GROUPS * (RMAX * qd + 2 * ro + q.half)) * NH + q.head) * (size_t)a.smax * HD) + q.lane;
 #pragma unroll
   for (int t = 0; t < KV_T; ++t) {
     const int ro = t / (KV_T / 2), which = (t / (KV_T / 4)) & 1, i = 4 * (t % (KV_T / 4)) + q.cw;
@@ -619,8 +634,8 @@ __device__ __forceinline__ void kv_stage_load(const MegaArgs& a, const Ctx& q, i
   }
 }
 
-__device__ __forceinline__ void kv_stage_store(const Ctx& q, int extra, const KvStage& st) {
-  const KvRows k = kv_rows(q, extra);
+__device__ __forceinline__ void kv_stage_store(const Ctx& q, int qd, int extra, const KvStage& st) {
+  const KvRows k = kv_rows(q, qd, extra);
 #pragma unroll
   for (int t = 0; t < KV_T; ++t) {
     const int ro = t / (KV_T / 2), which = (t / (KV_T / 4)) & 1, i = 4 * (t % (KV_T / 4)) + q.cw;
@@ -628,138 +643,183 @@ __device__ __forceinline__ void kv_stage_store(const Ctx& q, int extra, const Kv
   }
 }
 
+// MULTI = false: the group has ONE quad (B <= 32), the quad loops below run once with qd = 0 and fold away.
+// MULTI = true (32 < B <= 128): a group serves up to QMAX quads.  Every phase of a layer is run for quad 0, 1, ... in turn with
+// the weights the compute waves already hold; each quad has its own hop buffers, so while a member works on quad q the other
+// members' publishes of quad q + 1 are already on their way: the hop latency that a single quad waits out four times per layer
+// is overlapped with the other quads' compute, and the weights are still streamed once per layer.
+template <bool MULTI>
 __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, const StepParams& sp) {
   Ctx q = c0;
   unsigned char* smem = c0.smem;
-  const int R = c0.R;
+  const int Rtot = c0.Rtot;
+  const int nq = MULTI ? (Rtot + RMAX - 1) / RMAX : 1;
   const int V = a.V, EOS = a.V - 1;
-  constexpr bool sweeper = true;                     // every comm wave sweeps one row (row cw) and stages a quarter of the K/V
-  const bool sampler = c0.member < R && c0.cw == 0;  // wave 0 of member r samples local row r
+  const bool sampler = c0.member < Rtot && c0.cw == 0;   // wave 0 of member m samples the group's local row m (quad m / 4, row m % 4)
   const int EPS = 4 * a.L + 2;                       // hops per step
   unsigned char* seen = smem + L_SEEN;
   KvStage kvs;
-  kv_stage_load(a, q, 0, 0, kvs);
-  kv_stage_store(q, 0, kvs);                         // layer 0's image (the attention waves read it after B1 + two compute barriers)
+  set_quad(q, 0);
+  kv_stage_load(a, q, 0, 0, 0, kvs);
+  kv_stage_store(q, 0, 0, kvs);                      // layer 0's image of quad 0 (the attention waves read it after B1 + two compute barriers)
   // LayerNorm parameters of the current layer, loaded in P1's poll-free stretch (a load issued right before a sweep would sit
   // in front of its polls: a wave's memory operations return in order): norm1 for hop C, norm2 for the next hop A / the tail
   float gC[8], bC[8], gA[8], bA[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) gC[k] = bC[k] = gA[k] = bA[k] = 0.f;
+  const int ra = c0.cw;                              // this wave's row of every quad
   for (int s = 0; s < a.nsteps; ++s) {
     const unsigned ep0 = a.ep_base + (unsigned)s * (unsigned)EPS;  // epoch of hop i of this step = ep0 + i + 1
     for (int l = 0; l < a.L; ++l) {
       const float* lp = a.fpack + (size_t)l * FP_LAYER;
-      relaunder(q);
-      q.hop = hop_slot(q, s, l);
-      q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer;
-      MG_STAMP(q, 0);
-      const int ra = q.cw;                             // this wave's row
-      // ---- hop A: y of the previous layer (or the step's input embedding) -> LayerNorm -> XS / XRES
-      if (sweeper) {
-        const unsigned ep = ep0 + 4 * l + 1;
-        if (ra < R) {
-          u4v qa[4];
-          const bool has_ln = l > 0;                       // layer 0's input is the embedding itself
-          bool ok = true;
-          if (s == 0 && l == 0) {
-            const float* ya = a.ybuf + (size_t)(q.group + MG_GROUPS * ra) * D + 2 * q.lane;
+      // ================= P1 of every quad: hop A -> LayerNorm; the compute waves run QKV, append and attention
+      for (int qd = 0; qd < nq; ++qd) {
+        relaunder(q);
+        set_quad(q, qd);
+        const int R = q.R;
+        q.hop = hop_slot(q, s, l);
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == 0;
+        MG_STAMP(q, 0);
+        // ---- hop A: y of the previous layer (or the step's input embedding) -> LayerNorm -> XS / XRES
+        {
+          const unsigned ep = ep0 + 4 * l + 1;
+          if (ra < R) {
+            u4v qa[4];
+            const bool has_ln = l > 0;                       // layer 0's input is the embedding itself
+            bool ok = true;
+            if (s == 0 && l == 0) {
+              const float* ya = a.ybuf + (size_t)batch_row(q, ra) * D + 2 * q.lane;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const f2 y2 = *(const f2*)(ya + j * 128); qa[j] = (u4v){__float_as_uint(y2[0]), 0u, __float_as_uint(y2[1]), 0u}; }
-          } else {
-            ok = sweep_wide<4>(q, q.hop + HOP_A + ra * 512, ep, qa, 1u, a.hint_mask & 1);
+              for (int j = 0; j < 4; ++j) { const f2 y2 = *(const f2*)(ya + j * 128); qa[j] = (u4v){__float_as_uint(y2[0]), 0u, __float_as_uint(y2[1]), 0u}; }
+            } else {
+              ok = sweep_wide<4>(q, q.hop + HOP_A + ra * 512, ep, qa, 1u, a.hint_mask & 1);
+            }
+            if (ok) ln_row_wide(q, ra, qa, has_ln ? gA : nullptr, bA);
           }
-          if (ok) ln_row_wide(q, ra, qa, has_ln ? gA : nullptr, bA);
-        }
-        if (l == 0 && s > 0 && q.cw == 0) {
-          // row state published by the samplers with the embedding: {active} per row
-          unsigned sv[1];
-          if (sweep<1>(q, q.hop + HOP_ST, R, ep, sv, 2u) && q.lane < R) {
-            const int was = st_active(q)[q.lane], now = (int)(sv[0] & 1u);
-            if (was) { st_step(q)[q.lane] += 1; if (now) st_kvlen(q)[q.lane] += 1; }
-            st_active(q)[q.lane] = now;
+          if (l == 0 && s > 0 && qd == 0 && q.cw == 0) {
+            // row state published by the samplers with the embedding: {active} per row; ALL quads' rows here, in front of
+            // quad 0's first barrier, so that every later slot of the step (K/V prefetch, exit test) sees the step's state
+            for (int q2 = 0; q2 < nq; ++q2) {
+              Ctx t = q;
+              set_quad(t, q2);
+              unsigned sv[1];
+              if (sweep<1>(t, hop_slot(t, s, l) + HOP_ST, t.R, ep, sv, 2u) && t.lane < t.R) {
+                const int was = st_active(t)[t.lane], now = (int)(sv[0] & 1u);
+                if (was) { st_step(t)[t.lane] += 1; if (now) st_kvlen(t)[t.lane] += 1; }
+                st_active(t)[t.lane] = now;
+              }
+            }
           }
         }
-      }
-      MG_STAMP(q, 1);
-      MG_BAR();                                                          // B1
-      if (*st_abort(q)) return;
-      if (l == 0 && s > 0 && group_done(q)) return;                      // every row of the group has finished
-      MG_STAMP(q, 2);
-      // next layer's K/V (across the step boundary the rows hold one more position: appended at this step's layer 0);
-      // the compute waves run the QKV GEMM, the reduce and the attention meanwhile, synchronised among themselves
-      const int kv_nl = l + 1 < a.L ? l + 1 : 0, kv_extra = l + 1 < a.L ? 0 : 1;
-      const bool kv_more = l + 1 < a.L || s + 1 < a.nsteps;
-      if (kv_more) kv_stage_load(a, q, kv_nl, kv_extra, kvs);
+        MG_STAMP(q, 1);
+        MG_BAR();                                                          // B1
+        if (*st_abort(q)) return;
+        if (l == 0 && s > 0 && qd == 0 && group_done(q)) return;           // every row of the group has finished
+        MG_STAMP(q, 2);
+        // K/V of the NEXT slot's quad: the next quad of this layer, else quad 0 of the next layer (across the step boundary the
+        // rows hold one more position: appended at this step's layer 0); the compute waves run the QKV GEMM, the reduce and
+        // the attention meanwhile, synchronised among themselves
+        const bool kv_same = qd + 1 < nq;
+        const int kv_nq = kv_same ? qd + 1 : 0;
+        const int kv_nl = kv_same ? l : (l + 1 < a.L ? l + 1 : 0), kv_extra = (kv_same || l + 1 < a.L) ? 0 : 1;
+        const bool kv_more = kv_same || l + 1 < a.L || s + 1 < a.nsteps;
+        if (kv_more) kv_stage_load(a, q, kv_nl, kv_nq, kv_extra, kvs);
+        if (qd + 1 == nq) {       // after the LAST quad's hop A: every quad's LayerNorm above still needed the previous layer's norm2
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int el = (k >> 1) * 128 + 2 * q.lane + (k & 1);      // the element sweep_wide<4> delivers in slot k
-        gC[k] = lp[FP_N1W + el]; bC[k] = lp[FP_N1B + el];
-        gA[k] = lp[FP_N2W + el]; bA[k] = lp[FP_N2B + el];
-      }
-      MG_STAMP(q, 4);
-      MG_BAR();                                                          // B4: the attention is done, the K/V image is free
-      MG_STAMP(q, 5);
-      relaunder(q);
-      if (kv_more) kv_stage_store(q, kv_extra, kvs);
-      // ---- hop B: attention output of all heads -> AT
-      if (sweeper && ra < R) {
-        u4v qb[2];
-        if (sweep_wide<2>(q, q.hop + HOP_B + ra * 256, ep0 + 4 * l + 2, qb, 3u, a.hint_mask & 2)) {
-          unsigned* at = (unsigned*)(smem + L_AT) + ra * (XS_LD / 2) + 2 * q.lane;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) *(u2v*)(at + j * 128) = (u2v){qb[j][0], qb[j][2]};
+          for (int k = 0; k < 8; ++k) {
+            const int el = (k >> 1) * 128 + 2 * q.lane + (k & 1);      // the element sweep_wide<4> delivers in slot k
+            gC[k] = lp[FP_N1W + el]; bC[k] = lp[FP_N1B + el];
+            gA[k] = lp[FP_N2W + el]; bA[k] = lp[FP_N2B + el];
+          }
         }
+        MG_STAMP(q, 4);
+        MG_BAR();                                                          // B4: the attention is done, the K/V image is free
+        MG_STAMP(q, 5);
+        relaunder(q);
+        if (kv_more) kv_stage_store(q, kv_nq, kv_extra, kvs);
       }
-      MG_STAMP(q, 6);
-      MG_BAR();                                                          // B1
-      if (*st_abort(q)) return;
-      MG_STAMP(q, 7);
-      MG_BAR();                                                          // B2
-      MG_STAMP(q, 8);
-      relaunder(q);
-      // ---- hop C: y1 -> LayerNorm1 -> XS / XRES
-      if (sweeper && ra < R) {
-        u4v qc[4];
-        if (sweep_wide<4>(q, q.hop + HOP_C + ra * 512, ep0 + 4 * l + 3, qc, 4u, a.hint_mask & 4)) ln_row_wide(q, ra, qc, gC, bC);
-      }
-      MG_STAMP(q, 9);
-      MG_BAR();                                                          // B1
-      if (*st_abort(q)) return;
-      MG_STAMP(q, 10);
-      MG_BAR();                                                          // B2
-      MG_STAMP(q, 11);
-      relaunder(q);
-      // ---- hop D: h -> HS
-      if (sweeper && ra < R) {
-        u4v qd[8];
-        if (sweep_wide<8>(q, q.hop + HOP_D + ra * 1024, ep0 + 4 * l + 4, qd, 5u, a.hint_mask & 8)) {
-          unsigned* hs = (unsigned*)(smem + L_HS) + ra * (HS_LD / 2) + 2 * q.lane;
+      // ================= P2 of every quad: hop B (attention output of all heads) -> AT
+      for (int qd = 0; qd < nq; ++qd) {
+        relaunder(q);
+        set_quad(q, qd);
+        q.hop = hop_slot(q, s, l);
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == 0;
+        if (ra < q.R) {
+          u4v qb[2];
+          if (sweep_wide<2>(q, q.hop + HOP_B + ra * 256, ep0 + 4 * l + 2, qb, 3u, a.hint_mask & 2)) {
+            unsigned* at = (unsigned*)(smem + L_AT) + ra * (XS_LD / 2) + 2 * q.lane;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) *(u2v*)(hs + j * 128) = (u2v){qd[j][0], qd[j][2]};
+            for (int j = 0; j < 2; ++j) *(u2v*)(at + j * 128) = (u2v){qb[j][0], qb[j][2]};
+          }
         }
+        MG_STAMP(q, 6);
+        MG_BAR();                                                          // B1
+        if (*st_abort(q)) return;
+        MG_STAMP(q, 7);
+        MG_BAR();                                                          // B2
+        MG_STAMP(q, 8);
       }
-      MG_STAMP(q, 12);
-      MG_BAR();                                                          // B1
-      if (*st_abort(q)) return;
-      MG_STAMP(q, 13);
-      MG_BAR();                                                          // B2
-      MG_STAMP(q, 14);
+      // ================= P3 of every quad: hop C (y1) -> LayerNorm1 -> XS / XRES
+      for (int qd = 0; qd < nq; ++qd) {
+        relaunder(q);
+        set_quad(q, qd);
+        q.hop = hop_slot(q, s, l);
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == 0;
+        if (ra < q.R) {
+          u4v qc[4];
+          if (sweep_wide<4>(q, q.hop + HOP_C + ra * 512, ep0 + 4 * l + 3, qc, 4u, a.hint_mask & 4)) ln_row_wide(q, ra, qc, gC, bC);
+        }
+        MG_STAMP(q, 9);
+        MG_BAR();                                                          // B1
+        if (*st_abort(q)) return;
+        MG_STAMP(q, 10);
+        MG_BAR();                                                          // B2
+        MG_STAMP(q, 11);
+      }
+      // ================= P4 of every quad: hop D (FFN hidden) -> HS
+      for (int qd = 0; qd < nq; ++qd) {
+        relaunder(q);
+        set_quad(q, qd);
+        q.hop = hop_slot(q, s, l);
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == 0;
+        if (ra < q.R) {
+          u4v qd8[8];
+          if (sweep_wide<8>(q, q.hop + HOP_D + ra * 1024, ep0 + 4 * l + 4, qd8, 5u, a.hint_mask & 8)) {
+            unsigned* hs = (unsigned*)(smem + L_HS) + ra * (HS_LD / 2) + 2 * q.lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *(u2v*)(hs + j * 128) = (u2v){qd8[j][0], qd8[j][2]};
+          }
+        }
+        MG_STAMP(q, 12);
+        MG_BAR();                                                          // B1
+        if (*st_abort(q)) return;
+        MG_STAMP(q, 13);
+        MG_BAR();                                                          // B2
+        MG_STAMP(q, 14);
+      }
     }
-    relaunder(q);
-    // ---- tail: hop A' -> LayerNorm2 of the last layer -> XS; then the samplers
-    q.hop = hop_slot(q, s, a.L);
+    // ---- tail: hop A' -> LayerNorm2 of the last layer -> XS, logits by the compute waves; quad after quad
     const unsigned epA = ep0 + 4 * a.L + 1, epE = ep0 + 4 * a.L + 2;
-    if (sweeper && q.cw < R) {
-      const int ra = q.cw;
-      u4v qa[4];
-      if (sweep_wide<4>(q, q.hop + HOP_A + ra * 512, epA, qa, 6u, a.hint_mask & 1)) ln_row_wide(q, ra, qa, gA, bA);   // norm2 of the last layer
+    for (int qd = 0; qd < nq; ++qd) {
+      relaunder(q);
+      set_quad(q, qd);
+      q.hop = hop_slot(q, s, a.L);
+      q.prof_on = false;
+      if (ra < q.R) {
+        u4v qa[4];
+        if (sweep_wide<4>(q, q.hop + HOP_A + ra * 512, epA, qa, 6u, a.hint_mask & 1)) ln_row_wide(q, ra, qa, gA, bA);   // norm2 of the last layer
+      }
+      MG_BAR();                                                            // B1
+      if (*st_abort(q)) return;
+      MG_BAR();                                                            // B2
     }
-    MG_BAR();                                                            // B1
-    if (*st_abort(q)) return;
-    MG_BAR();                                                            // B2
-    // ---- sampling of local row `member` (reference utils.py:140-199, t2s_model.py:706-769)
+    // ---- sampling of the group's local row `member` (reference utils.py:140-199, t2s_model.py:706-769): after the logits of
+    // every quad have been published, so that the samplers of all quads work side by side
     if (sampler) {
-      const int r = q.member, b = q.group + MG_GROUPS * r;
+      relaunder(q);
+      set_quad(q, q.member / RMAX);
+      q.hop = hop_slot(q, s, a.L);
+      const int r = q.member % RMAX, b = batch_row(q, r);
       const unsigned epN = ep0 + (unsigned)EPS + 1;                      // hop A of the next step's layer 0
       const int was_active = st_active(q)[r];
       int now_active = 0;
@@ -829,21 +889,37 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
   }
 }
 
+template <bool MULTI>
 __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
   Ctx q = c0;
   unsigned char* smem = c0.smem;
-  const int R = c0.R;
+  const int Rtot = c0.Rtot;
+  const int nq = MULTI ? (Rtot + RMAX - 1) / RMAX : 1;
   const int V = a.V;
   const int EPS = 4 * a.L + 2;
-  // own rows of this member (attention): local rows 2*ro + half, ro = 0, 1
+  // own rows of this member (attention): rows 2*ro + half of the current quad, ro = 0, 1
   auto kv_row_base = [&](int layer, int which, int r) -> const _Float16* {
-    const int b = q.group + MG_GROUPS * r;
+    const int b = batch_row(q, r);
     return a.kv + ((size_t)(layer * 2 + which)) * a.kv_layer_stride + ((size_t)b * NH + q.head) * (size_t)a.smax * HD;
   };
   const h8* wp = a.wpack;
   auto p1_src = [&](int layer) { return wp + ((size_t)layer * LAYER_HALFS + ((size_t)q.head * 4 + q.cw) * WI_P1 * 512) / 8 + q.lane; };
   auto pm_src = [&](int layer, int off) {
     return wp + ((size_t)layer * LAYER_HALFS + P1_HALFS + (((size_t)q.member * 4 + q.cw) * (WI_P2 + WI_P3 + WI_P4) + off) * 512) / 8 + q.lane;
+  };
+  // residual operands of the out-projection (LN(y) of hop A) and of FFN2 (LN1(y1) of hop C) for the reducing wave's lanes.
+  // One quad: read from XRES when needed.  Several quads: XRES is overwritten by the next quad's LayerNorm before the phase
+  // that needs it comes round, so the member's 16 columns of every row are parked per quad (f4 per lane, 1 KB per quad).
+  auto rs_slot = [&](int which, int qd) { return (f4*)(smem + L_RS) + (which * QMAX + qd) * 64 + q.lane; };
+  // K/V arena append of this step's k, v (own rows), from the LDS copy the attention used
+  auto arena_append = [&](int l) {
+    const int ro = q.lane >> 4, which = (q.lane >> 3) & 1, e = 4 * (q.lane & 7), r = 2 * ro + q.half;
+    if (r < q.R && st_active(q)[r]) {
+      const int pos = st_kvlen(q)[r];
+      if (pos < a.smax)
+        *(h4*)(const_cast<_Float16*>(kv_row_base(l, which, r)) + (size_t)pos * HD + e) =
+            *(const h4*)((const _Float16*)(smem + L_QKV) + (ro * 3 + 1 + which) * HD + e);
+    }
   };
   // P1's slice is held as two halves (tiles q0 q1 k0 | k1 v0 v1): the second half is requested one phase later than the
   // first, so that FFN2's slice + the whole next P1 slice are never live together (160 + operands would spill)
@@ -858,238 +934,276 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
     const unsigned ep0 = a.ep_base + (unsigned)s * (unsigned)EPS;
     for (int l = 0; l < a.L; ++l) {
       const float* lp = a.fpack + (size_t)l * FP_LAYER;
-      relaunder(q);
-      q.hop = hop_slot(q, s, l);
-      q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer;
-      MG_STAMP(q, 0);
-      // ================= P1: q,k,v of head `head` for the own rows, K/V append, attention
-      // lane j < 24 of every wave reduces 4 values of q | k | v of the wave's OWN attention row (see after B2)
-      const int rj_which = (q.lane >> 3) % 3, rj_e = 4 * (q.lane & 7);
-      const f4 p1_bias = q.lane < 24 ? *(const f4*)(lp + FP_QKVB + rj_which * D + q.head * HD + rj_e) : (f4){0.f, 0.f, 0.f, 0.f};
-      MG_STAMP(q, 1);
-      MG_BAR();                                                          // B1: XS / XRES hold LN(y)
-      if (*st_abort(q)) return;
-      if (l == 0 && s > 0 && group_done(q)) return;
-      MG_STAMP(q, 2);
-      wload(wB, pm_src(l, 0));
-      gemm_chunk<3>(q, wA0, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 6);
-      gemm_chunk<3>(q, wA1, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 6 + 3);
-      MG_STAMP(q, 3);
-      compute_barrier(q, cgen);                                          // B2 (compute waves only)
-      if (*st_abort(q)) return;
-      MG_STAMP(q, 4);
-      {
-        // split-K reduce of q, k, v (+ bias) by the wave that consumes them: each attention wave sums the 96 values of ITS row
-        // (both waves of a row do, and write identical bytes), so that no barrier stands between the reduce and the attention
-        // -- the workgroup-wide reduce + compute-only barrier here were 0.7 us of every layer (stamps 4-7).  Same summation
-        // order as before: ((w0 + w1) + w2) + w3 + bias.
-        const f4* red = (const f4*)(smem + L_RED);
-        _Float16* qkv_s = (_Float16*)(smem + L_QKV);
-        const int ro = q.cw / 2, r = 2 * ro + q.half;
-        if (q.lane < 24 && r < R) {
-          const int tile = rj_which * 2 + (rj_e >> 4), ln = r + 16 * ((rj_e & 15) >> 2);
-          const f4 v0 = red[(0 * 6 + tile) * 64 + ln], v1 = red[(1 * 6 + tile) * 64 + ln], v2 = red[(2 * 6 + tile) * 64 + ln],
-                   v3 = red[(3 * 6 + tile) * 64 + ln];
-          f4 v = v0;
-          v += v1; v += v2; v += v3;
-          v += p1_bias;
-          const h4 ov = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-          *(h4*)(qkv_s + (ro * 3 + rj_which) * HD + rj_e) = ov;    // the arena append of k, v follows in P2 (see there)
-        }
-        asm volatile("" ::: "memory");                      // the attention's reads of qkv_s stay behind the writes (same wave: in order)
-        MG_STAMP(q, 5);
-      }
-      MG_STAMP(q, 6);
-      MG_STAMP(q, 7);
-      attention_part<2>(a, q, l, q.cw);
-      MG_STAMP(q, 8);
-      // the partials of a row's two waves meet through LDS.  This barrier is B4 itself (the attention has released the K/V
-      // image): the comm waves only have to ISSUE the next layer's K/V loads before it, which takes ~1.5 us since the row
-      // state is read once per call (it was 3.5 us, and a compute-only barrier stood here so that the publish did not wait)
-      MG_BAR();                                                          // B4
-      if (*st_abort(q)) return;
-      MG_STAMP(q, 9);
-      if (q.cw == 0) {
-        // combine the 2 waves of each own row; lane = ro * 32 + e
-        const float* s_m = (const float*)(smem + L_ATT);
-        const float* s_acc = s_m + 8;
-        const int ro = q.lane >> 5, e = q.lane & 31, r = 2 * ro + q.half;
-        float M = -INFINITY;
-#pragma unroll
-        for (int w = 0; w < 2; ++w) M = fmaxf(M, s_m[2 * ro + w]);
-        float o = 0.f;
-        if (M != -INFINITY) {
-          float Lsum = 0.f, num = 0.f;
-#pragma unroll
-          for (int w = 0; w < 2; ++w) {
-            const float mw = s_m[2 * ro + w];
-            const float ew = mw == -INFINITY ? 0.f : __expf(mw - M);
-            const float* pa = s_acc + (2 * ro + w) * 4 * 36;
-            Lsum += ((pa[32] + pa[36 + 32]) + (pa[72 + 32] + pa[108 + 32])) * ew;
-            num += ((pa[e] + pa[36 + e]) + (pa[72 + e] + pa[108 + e])) * ew;
-          }
-          o = num / Lsum;
-        }
-        const float o2 = dpp_f<DPP_QUAD_XOR1>(o);            // lane ^ 1
-        // 16 granules (one 128-B line) per own row, written by one wave instruction
-        if (r < R && !(e & 1)) gstore(q.hop + HOP_B + r * 256 + (q.head * HD + e) / 2, ep0 + 4 * l + 2, pack_h2(o, o2));
-      }
-      MG_STAMP(q, 10);
-      relaunder(q);
-      // ================= P2: out-projection columns [16 member, +16) + bias + residual -> y1
-      f4 p_bias = *(const f4*)(lp + FP_OUTB + 16 * q.member + 4 * (q.lane >> 4));
-      MG_STAMP(q, 11);
-      MG_BAR();                                                          // B1: AT holds the attention output
-      if (*st_abort(q)) return;
-      MG_STAMP(q, 12);
-      wload(wC, pm_src(l, WI_P2));
-      gemm_chunk<1>(q, wB, (const _Float16*)(smem + L_AT), XS_LD, q.cw, q.cw);
-      MG_STAMP(q, 13);
-      MG_BAR();                                                          // B2
-      MG_STAMP(q, 14);
-      if (q.cw == 0) {
-        const f4* red = (const f4*)(smem + L_RED);
-        const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
-        if (r < R) {
-          const f4 v0 = red[q.lane], v1 = red[64 + q.lane], v2 = red[128 + q.lane], v3 = red[192 + q.lane];
-          const f4 xr = *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
-          f4 v = v0;
-          v += v1; v += v2; v += v3;
-          v += p_bias;
-          v += xr;
-          *(f4*)((float*)(smem + L_STAGE) + r * 16 + 4 * (q.lane >> 4)) = v;
-        }
-        // transposed through LDS (same wave): lane = row * 16 + column, so each row's 16 granules = one 128-B line
-        // written whole by ONE store instruction (scattered 8-B write-through stores made every hop 2-3x slower)
-        // test hook (gsv_t2s_debug_stall, tests only): that member of group 0 skips ONE publish, so that the group's
-        // bounded waits must end the launch with an error instead of hanging
-        const bool stall = a.test_stall && q.member == a.test_stall - 1 && q.group == 0 && s == 2 && l == 3;
-        if (q.lane < R * 16 && !stall)
-          gstore(q.hop + HOP_C + (q.lane >> 4) * 512 + 16 * q.member + (q.lane & 15), ep0 + 4 * l + 3,
-                 __float_as_uint(((const float*)(smem + L_STAGE))[q.lane]));
-      }
-      if (q.cw == 1 && q.lane < 32) {   // wave 1 is idle while wave 0 publishes
-        // K/V arena append of this step's k, v (own rows), from the LDS copy the attention used.  Not in P1 where they are
-        // produced: there the store has to queue behind the comm waves' K/V burst of the next layer in the CU's memory
-        // pipeline (1.3 us of blocked issue in the stamps); nothing reads the arena row before the next step's staging.
-        const int ro = q.lane >> 4, which = (q.lane >> 3) & 1, e = 4 * (q.lane & 7), r = 2 * ro + q.half;
-        if (r < R && st_active(q)[r]) {
-          const int pos = st_kvlen(q)[r];
-          if (pos < a.smax)
-            *(h4*)(const_cast<_Float16*>(kv_row_base(l, which, r)) + (size_t)pos * HD + e) =
-                *(const h4*)((const _Float16*)(smem + L_QKV) + (ro * 3 + 1 + which) * HD + e);
-        }
-      }
-      relaunder(q);
-      // ================= P3: FFN1 columns [64 member, +64), ReLU -> h
-      p_bias = *(const f4*)(lp + FP_B1 + 64 * q.member + 32 * (q.cw & 1) + 4 * (q.lane >> 4));       // tiles 2 (cw & 1), +1
-      const f4 p_bias2 = *(const f4*)(lp + FP_B1 + 64 * q.member + 32 * (q.cw & 1) + 16 + 4 * (q.lane >> 4));
-      MG_STAMP(q, 15);
-      MG_BAR();                                                          // B1: XS / XRES hold LN1(y1)
-      if (*st_abort(q)) return;
-      MG_STAMP(q, 16);
-      wload(wD, pm_src(l, WI_P2 + WI_P3));
-      gemm_chunk<4>(q, wC, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 4);
-      MG_STAMP(q, 17);
-      MG_BAR();                                                          // B2
-      MG_STAMP(q, 18);
-      if (q.cw < 2) {
-        // waves 0 and 1 reduce tiles {0, 1} and {2, 3}: 32 columns = 16 half-pair granules = one 128-B line per row
-        const f4* red = (const f4*)(smem + L_RED);
-        const int r = q.lane & 15;
-        unsigned* stage = (unsigned*)(smem + L_STAGE) + q.cw * 256;
-        if (r < R) {
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt) {
-            const int tile = 2 * q.cw + tt;
-            const f4 v0 = red[(0 * 4 + tile) * 64 + q.lane], v1 = red[(1 * 4 + tile) * 64 + q.lane],
-                     v2 = red[(2 * 4 + tile) * 64 + q.lane], v3 = red[(3 * 4 + tile) * 64 + q.lane];
+      // ================= P1: q,k,v of head `head` for the own rows, attention (K/V append: see P2)
+      // (the next phase's weight slice is requested in EVERY quad's slot, not only the first: a request under a run-time
+      // `if (qd == 0)` inside the quad loop is a CONDITIONAL definition of the register array, which keeps the array's
+      // previous contents alive around the whole loop -- every slice live everywhere, ~100 spilled VGPRs.  The repeated
+      // requests hit L2 and rewrite the registers with the same bytes; no slot reads the array it requests)
+      for (int qd = 0; qd < nq; ++qd) {
+        const bool first = qd == 0;
+        relaunder(q);
+        set_quad(q, qd);
+        const int R = q.R;
+        q.hop = hop_slot(q, s, l);
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && first;
+        MG_STAMP(q, 0);
+        // lane j < 24 of every wave reduces 4 values of q | k | v of the wave's OWN attention row (see after B2)
+        const int rj_which = (q.lane >> 3) % 3, rj_e = 4 * (q.lane & 7);
+        const f4 p1_bias = q.lane < 24 ? *(const f4*)(lp + FP_QKVB + rj_which * D + q.head * HD + rj_e) : (f4){0.f, 0.f, 0.f, 0.f};
+        MG_STAMP(q, 1);
+        MG_BAR();                                                          // B1: XS / XRES hold LN(y)
+        if (*st_abort(q)) return;
+        if (first && l == 0 && s > 0 && group_done(q)) return;
+        MG_STAMP(q, 2);
+        wload(wB, pm_src(l, 0));                                           // every quad's slot (see the note above the loop)
+        gemm_chunk<3>(q, wA0, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 6);
+        gemm_chunk<3>(q, wA1, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 6 + 3);
+        if (MULTI && q.cw == 0 && (q.lane & 15) < R)                       // the out-projection's residual operand of this quad
+          *rs_slot(0, qd) = *(const f4*)((const float*)(smem + L_XRES) + (q.lane & 15) * D + 16 * q.member + 4 * (q.lane >> 4));
+        MG_STAMP(q, 3);
+        compute_barrier(q, cgen);                                          // B2 (compute waves only)
+        if (*st_abort(q)) return;
+        MG_STAMP(q, 4);
+        {
+          // split-K reduce of q, k, v (+ bias) by the wave that consumes them: each attention wave sums the 96 values of ITS row
+          // (both waves of a row do, and write identical bytes), so that no barrier stands between the reduce and the attention
+          // -- the workgroup-wide reduce + compute-only barrier here were 0.7 us of every layer (stamps 4-7).  Same summation
+          // order as before: ((w0 + w1) + w2) + w3 + bias.
+          const f4* red = (const f4*)(smem + L_RED);
+          _Float16* qkv_s = (_Float16*)(smem + L_QKV);
+          const int ro = q.cw / 2, r = 2 * ro + q.half;
+          if (q.lane < 24 && r < R) {
+            const int tile = rj_which * 2 + (rj_e >> 4), ln = r + 16 * ((rj_e & 15) >> 2);
+            const f4 v0 = red[(0 * 6 + tile) * 64 + ln], v1 = red[(1 * 6 + tile) * 64 + ln], v2 = red[(2 * 6 + tile) * 64 + ln],
+                     v3 = red[(3 * 6 + tile) * 64 + ln];
             f4 v = v0;
             v += v1; v += v2; v += v3;
-            v += tt == 0 ? p_bias : p_bias2;
-            const int w0 = r * 16 + tt * 8 + 2 * (q.lane >> 4);
-            stage[w0] = pack_h2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
-            stage[w0 + 1] = pack_h2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+            v += p1_bias;
+            const h4 ov = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            *(h4*)(qkv_s + (ro * 3 + rj_which) * HD + rj_e) = ov;    // the arena append of k, v follows (see arena_append)
           }
+          asm volatile("" ::: "memory");                      // the attention's reads of qkv_s stay behind the writes (same wave: in order)
+          MG_STAMP(q, 5);
         }
-        if (q.lane < R * 16)
-          gstore(q.hop + HOP_D + (q.lane >> 4) * 1024 + 32 * q.member + 16 * q.cw + (q.lane & 15), ep0 + 4 * l + 4, stage[q.lane]);
+        MG_STAMP(q, 6);
+        MG_STAMP(q, 7);
+        attention_part<2>(a, q, l, q.cw);
+        MG_STAMP(q, 8);
+        // the partials of a row's two waves meet through LDS.  This barrier is B4 itself (the attention has released the K/V
+        // image): the comm waves only have to ISSUE the next layer's K/V loads before it, which takes ~1.5 us since the row
+        // state is read once per call (it was 3.5 us, and a compute-only barrier stood here so that the publish did not wait)
+        MG_BAR();                                                          // B4
+        if (*st_abort(q)) return;
+        MG_STAMP(q, 9);
+        if (q.cw == 0) {
+          // combine the 2 waves of each own row; lane = ro * 32 + e
+          const float* s_m = (const float*)(smem + L_ATT);
+          const float* s_acc = s_m + 8;
+          const int ro = q.lane >> 5, e = q.lane & 31, r = 2 * ro + q.half;
+          float M = -INFINITY;
+#pragma unroll
+          for (int w = 0; w < 2; ++w) M = fmaxf(M, s_m[2 * ro + w]);
+          float o = 0.f;
+          if (M != -INFINITY) {
+            float Lsum = 0.f, num = 0.f;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+              const float mw = s_m[2 * ro + w];
+              const float ew = mw == -INFINITY ? 0.f : __expf(mw - M);
+              const float* pa = s_acc + (2 * ro + w) * 4 * 36;
+              Lsum += ((pa[32] + pa[36 + 32]) + (pa[72 + 32] + pa[108 + 32])) * ew;
+              num += ((pa[e] + pa[36 + e]) + (pa[72 + e] + pa[108 + e])) * ew;
+            }
+            o = num / Lsum;
+          }
+          const float o2 = dpp_f<DPP_QUAD_XOR1>(o);            // lane ^ 1
+          // 16 granules (one 128-B line) per own row, written by one wave instruction
+          if (r < R && !(e & 1)) gstore(q.hop + HOP_B + r * 256 + (q.head * HD + e) / 2, ep0 + 4 * l + 2, pack_h2(o, o2));
+        }
+        // several quads: the next quad's reduce overwrites the q/k/v copy before P2 comes round, so the arena append happens
+        // here (the comm waves' K/V burst of the next slot was issued a whole attention ago and has drained)
+        if (MULTI && q.cw == 1 && q.lane < 32) arena_append(l);
+        MG_STAMP(q, 10);
       }
-      relaunder(q);
+      // ================= P2: out-projection columns [16 member, +16) + bias + residual -> y1
+      for (int qd = 0; qd < nq; ++qd) {
+        const bool first = qd == 0;
+        relaunder(q);
+        set_quad(q, qd);
+        const int R = q.R;
+        q.hop = hop_slot(q, s, l);
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && first;
+        const f4 p_bias = *(const f4*)(lp + FP_OUTB + 16 * q.member + 4 * (q.lane >> 4));
+        MG_STAMP(q, 11);
+        MG_BAR();                                                          // B1: AT holds the attention output
+        if (*st_abort(q)) return;
+        MG_STAMP(q, 12);
+        wload(wC, pm_src(l, WI_P2));
+        gemm_chunk<1>(q, wB, (const _Float16*)(smem + L_AT), XS_LD, q.cw, q.cw);
+        MG_STAMP(q, 13);
+        MG_BAR();                                                          // B2
+        MG_STAMP(q, 14);
+        if (q.cw == 0) {
+          const f4* red = (const f4*)(smem + L_RED);
+          const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
+          if (r < R) {
+            const f4 v0 = red[q.lane], v1 = red[64 + q.lane], v2 = red[128 + q.lane], v3 = red[192 + q.lane];
+            const f4 xr = MULTI ? *rs_slot(0, qd) : *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
+            f4 v = v0;
+            v += v1; v += v2; v += v3;
+            v += p_bias;
+            v += xr;
+            *(f4*)((float*)(smem + L_STAGE) + r * 16 + 4 * (q.lane >> 4)) = v;
+          }
+          // transposed through LDS (same wave): lane = row * 16 + column, so each row's 16 granules = one 128-B line
+          // written whole by ONE store instruction (scattered 8-B write-through stores made every hop 2-3x slower)
+          // test hook (gsv_t2s_debug_stall, tests only): that member of group 0 skips ONE publish, so that the group's
+          // bounded waits must end the launch with an error instead of hanging
+          const bool stall = a.test_stall && q.member == a.test_stall - 1 && q.group == 0 && s == 2 && l == 3 && qd == 0;
+          if (q.lane < R * 16 && !stall)
+            gstore(q.hop + HOP_C + (q.lane >> 4) * 512 + 16 * q.member + (q.lane & 15), ep0 + 4 * l + 3,
+                   __float_as_uint(((const float*)(smem + L_STAGE))[q.lane]));
+        }
+        if (!MULTI && q.cw == 1 && q.lane < 32) {   // wave 1 is idle while wave 0 publishes
+          // K/V arena append: not in P1 where k, v are produced -- there the store has to queue behind the comm waves' K/V
+          // burst of the next layer in the CU's memory pipeline (1.3 us of blocked issue in the stamps); nothing reads the
+          // arena row before the next step's staging
+          arena_append(l);
+        }
+      }
+      // ================= P3: FFN1 columns [64 member, +64), ReLU -> h
+      for (int qd = 0; qd < nq; ++qd) {
+        const bool first = qd == 0;
+        relaunder(q);
+        set_quad(q, qd);
+        const int R = q.R;
+        q.hop = hop_slot(q, s, l);
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && first;
+        const f4 p_bias = *(const f4*)(lp + FP_B1 + 64 * q.member + 32 * (q.cw & 1) + 4 * (q.lane >> 4));       // tiles 2 (cw & 1), +1
+        const f4 p_bias2 = *(const f4*)(lp + FP_B1 + 64 * q.member + 32 * (q.cw & 1) + 16 + 4 * (q.lane >> 4));
+        MG_STAMP(q, 15);
+        MG_BAR();                                                          // B1: XS / XRES hold LN1(y1)
+        if (*st_abort(q)) return;
+        MG_STAMP(q, 16);
+        wload(wD, pm_src(l, WI_P2 + WI_P3));
+        gemm_chunk<4>(q, wC, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 4);
+        if (MULTI && q.cw == 2 && (q.lane & 15) < R)                       // FFN2's residual operand of this quad
+          *rs_slot(1, qd) = *(const f4*)((const float*)(smem + L_XRES) + (q.lane & 15) * D + 16 * q.member + 4 * (q.lane >> 4));
+        MG_STAMP(q, 17);
+        MG_BAR();                                                          // B2
+        MG_STAMP(q, 18);
+        if (q.cw < 2) {
+          // waves 0 and 1 reduce tiles {0, 1} and {2, 3}: 32 columns = 16 half-pair granules = one 128-B line per row
+          const f4* red = (const f4*)(smem + L_RED);
+          const int r = q.lane & 15;
+          unsigned* stage = (unsigned*)(smem + L_STAGE) + q.cw * 256;
+          if (r < R) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+              const int tile = 2 * q.cw + tt;
+              const f4 v0 = red[(0 * 4 + tile) * 64 + q.lane], v1 = red[(1 * 4 + tile) * 64 + q.lane],
+                       v2 = red[(2 * 4 + tile) * 64 + q.lane], v3 = red[(3 * 4 + tile) * 64 + q.lane];
+              f4 v = v0;
+              v += v1; v += v2; v += v3;
+              v += tt == 0 ? p_bias : p_bias2;
+              const int w0 = r * 16 + tt * 8 + 2 * (q.lane >> 4);
+              stage[w0] = pack_h2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+              stage[w0 + 1] = pack_h2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+            }
+          }
+          if (q.lane < R * 16)
+            gstore(q.hop + HOP_D + (q.lane >> 4) * 1024 + 32 * q.member + 16 * q.cw + (q.lane & 15), ep0 + 4 * l + 4, stage[q.lane]);
+        }
+      }
       // ================= P4: FFN2 columns [16 member, +16) over K = 2048 (each wave chains its 4 chunks of 128, 4 partials) -> y2
-      p_bias = *(const f4*)(lp + FP_B2 + 16 * q.member + 4 * (q.lane >> 4));
-      MG_STAMP(q, 19);
-      MG_BAR();                                                          // B1: HS holds the FFN hidden
-      if (*st_abort(q)) return;
-      MG_STAMP(q, 20);
-      if (l + 1 < a.L) wload(wA0, p1_src(l + 1));
-      else wload(wA0, a.lpack + (((size_t)q.member * 4 + q.cw) * WI_LG * 512) / 8 + q.lane);
-      {
-        const int rowl = q.lane & 15, kg = q.lane >> 4;
-        f4* red = (f4*)(smem + L_RED);
-        // one accumulator over the wave's four 128-wide chunks (the MFMA forwards a dependent accumulator without a stall):
-        // ONE partial per wave like the other phases, instead of 16 per workgroup through LDS
-        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+      for (int qd = 0; qd < nq; ++qd) {
+        relaunder(q);
+        set_quad(q, qd);
+        const int R = q.R;
+        q.hop = hop_slot(q, s, l);
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == 0;
+        const f4 p_bias = *(const f4*)(lp + FP_B2 + 16 * q.member + 4 * (q.lane >> 4));
+        MG_STAMP(q, 19);
+        MG_BAR();                                                          // B1: HS holds the FFN hidden
+        if (*st_abort(q)) return;
+        MG_STAMP(q, 20);
+        if (l + 1 < a.L) wload(wA0, p1_src(l + 1));                        // P1 has finished with wA0 for every quad
+        else wload(wA0, a.lpack + (((size_t)q.member * 4 + q.cw) * WI_LG * 512) / 8 + q.lane);
+        {
+          const int rowl = q.lane & 15, kg = q.lane >> 4;
+          f4* red = (f4*)(smem + L_RED);
+          // one accumulator over the wave's four 128-wide chunks (the MFMA forwards a dependent accumulator without a stall):
+          // ONE partial per wave like the other phases, instead of 16 per workgroup through LDS
+          f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int kc = 4 * q.cw + cc;
-          const _Float16* bp = (const _Float16*)(smem + L_HS) + (rowl & (RMAX - 1)) * HS_LD + kc * 128 + 8 * kg;
+          for (int cc = 0; cc < 4; ++cc) {
+            const int kc = 4 * q.cw + cc;
+            const _Float16* bp = (const _Float16*)(smem + L_HS) + (rowl & (RMAX - 1)) * HS_LD + kc * 128 + 8 * kg;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wD[cc * 4 + ks], *(const h8*)(bp + 32 * ks), acc, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);       // keep the 16 operand reads from being hoisted in front of the first MFMA
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wD[cc * 4 + ks], *(const h8*)(bp + 32 * ks), acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);       // keep the 16 operand reads from being hoisted in front of the first MFMA
+          }
+          red[q.cw * 64 + q.lane] = acc;
         }
-        red[q.cw * 64 + q.lane] = acc;
-      }
-      // second half of the next P1 slice: FFN2's slice is dead now, and the request is still in front of the publish
-      wload(wA1, p1_src(l + 1 < a.L ? l + 1 : 0) + (size_t)(WI_P1 / 2) * 64);
-      MG_STAMP(q, 21);
-      MG_BAR();                                                          // B2
-      MG_STAMP(q, 22);
-      if (q.cw == 0) {
-        const f4* red = (const f4*)(smem + L_RED);
-        const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
-        if (r < R) {
-          const f4 v0 = red[q.lane], v1 = red[64 + q.lane], v2 = red[128 + q.lane], v3 = red[192 + q.lane];
-          const f4 xr = *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
-          f4 v = v0;
-          v += v1; v += v2; v += v3;
-          v += p_bias;
-          v += xr;
-          // y2 feeds hop A of the next layer, or hop A' (the logits' LayerNorm) after the last layer
-          *(f4*)((float*)(smem + L_STAGE) + r * 16 + 4 * (q.lane >> 4)) = v;
+        // second half of the next P1 slice: this quad's FFN2 is done, and the request is still in front of the publish
+        wload(wA1, p1_src(l + 1 < a.L ? l + 1 : 0) + (size_t)(WI_P1 / 2) * 64);
+        MG_STAMP(q, 21);
+        MG_BAR();                                                          // B2
+        MG_STAMP(q, 22);
+        if (q.cw == 0) {
+          const f4* red = (const f4*)(smem + L_RED);
+          const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
+          if (r < R) {
+            const f4 v0 = red[q.lane], v1 = red[64 + q.lane], v2 = red[128 + q.lane], v3 = red[192 + q.lane];
+            const f4 xr = MULTI ? *rs_slot(1, qd) : *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
+            f4 v = v0;
+            v += v1; v += v2; v += v3;
+            v += p_bias;
+            v += xr;
+            // y2 feeds hop A of the next layer, or hop A' (the logits' LayerNorm) after the last layer
+            *(f4*)((float*)(smem + L_STAGE) + r * 16 + 4 * (q.lane >> 4)) = v;
+          }
+          const unsigned ep = l + 1 < a.L ? ep0 + 4 * (l + 1) + 1 : ep0 + 4 * a.L + 1;
+          if (q.lane < R * 16)
+            gstore(hop_slot(q, s, l + 1) + HOP_A + (q.lane >> 4) * 512 + 16 * q.member + (q.lane & 15), ep,
+                   __float_as_uint(((const float*)(smem + L_STAGE))[q.lane]));
         }
-        const unsigned ep = l + 1 < a.L ? ep0 + 4 * (l + 1) + 1 : ep0 + 4 * a.L + 1;
-        if (q.lane < R * 16)
-          gstore(hop_slot(q, s, l + 1) + HOP_A + (q.lane >> 4) * 512 + 16 * q.member + (q.lane & 15), ep,
-                 __float_as_uint(((const float*)(smem + L_STAGE))[q.lane]));
+        MG_STAMP(q, 23);
       }
-      MG_STAMP(q, 23);
     }
     // ================= tail: logits split over the members (tiles member, member + 32, and tile 64 on member 0)
     const unsigned epE = ep0 + 4 * a.L + 2;
-    relaunder(q);
-    q.hop = hop_slot(q, s, a.L);
-    MG_BAR();                                                            // B1: XS holds LN2(y) of the last layer
-    if (*st_abort(q)) return;
-    gemm_chunk<3>(q, wA0, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 3);
-    wload(wA0, p1_src(0));                                               // next step's layer 0 (two hops away; wA1 is there already)
-    MG_BAR();                                                            // B2
-    if (q.cw < 3) {
-      const f4* red = (const f4*)(smem + L_RED);
-      const int t = q.cw, r = q.lane & 15;
-      const int tile = t == 0 ? q.member : (t == 1 ? q.member + 32 : 64);
-      float* stage = (float*)(smem + L_STAGE) + q.cw * 256;
-      if (r < R) {
-        f4 v = red[(0 * 3 + t) * 64 + q.lane];
-        v += red[(1 * 3 + t) * 64 + q.lane]; v += red[(2 * 3 + t) * 64 + q.lane]; v += red[(3 * 3 + t) * 64 + q.lane];
-        *(f4*)(stage + r * 16 + 4 * (q.lane >> 4)) = v;
+    for (int qd = 0; qd < nq; ++qd) {
+      relaunder(q);
+      set_quad(q, qd);
+      const int R = q.R;
+      q.hop = hop_slot(q, s, a.L);
+      q.prof_on = false;
+      MG_BAR();                                                            // B1: XS holds LN2(y) of the last layer
+      if (*st_abort(q)) return;
+      gemm_chunk<3>(q, wA0, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 3);
+      if (!MULTI) wload(wA0, p1_src(0));                                   // next step's layer 0 (two hops away; wA1 is there already)
+      MG_BAR();                                                            // B2
+      if (q.cw < 3) {
+        const f4* red = (const f4*)(smem + L_RED);
+        const int t = q.cw, r = q.lane & 15;
+        const int tile = t == 0 ? q.member : (t == 1 ? q.member + 32 : 64);
+        float* stage = (float*)(smem + L_STAGE) + q.cw * 256;
+        if (r < R) {
+          f4 v = red[(0 * 3 + t) * 64 + q.lane];
+          v += red[(1 * 3 + t) * 64 + q.lane]; v += red[(2 * 3 + t) * 64 + q.lane]; v += red[(3 * 3 + t) * 64 + q.lane];
+          *(f4*)(stage + r * 16 + 4 * (q.lane >> 4)) = v;
+        }
+        if (q.lane < R * 16 && (t < 2 || q.member == 0) && 16 * tile + (q.lane & 15) < V)
+          gstore(q.hop + HOP_E + (q.lane >> 4) * VPAD + 16 * tile + (q.lane & 15), epE, __float_as_uint(stage[q.lane]));
       }
-      if (q.lane < R * 16 && (t < 2 || q.member == 0) && 16 * tile + (q.lane & 15) < V)
-        gstore(q.hop + HOP_E + (q.lane >> 4) * VPAD + 16 * tile + (q.lane & 15), epE, __float_as_uint(stage[q.lane]));
     }
+    // several quads: the logits slice is read by every quad's slot, the next step's first slice follows the last one
+    if (MULTI) wload(wA0, p1_src(0));
   }
 }
 
+template <bool MULTI>
 __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Ctx c;
@@ -1112,8 +1226,8 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
       ((volatile int*)smem)[1] = (int)t;
     }
     __syncthreads();
-    const int xcd = ((volatile int*)smem)[0], t = ((volatile int*)smem)[1];
-    __syncthreads();
+    const int xcd = __builtin_amdgcn_readfirstlane(((volatile int*)smem)[0]), t = __builtin_amdgcn_readfirstlane(((volatile int*)smem)[1]);
+    __syncthreads();                                 // (uniform values: keep them, and everything derived from them, in SGPRs)
     if (t >= 32) {
       if (tid == 0) { __hip_atomic_store((gu32*)a.err + 3, 0x50u, RLX_AGENT); __hip_atomic_store((gu32*)a.err, 1u, RLX_AGENT); }
       return;
@@ -1122,9 +1236,12 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   } else if (a.map_shared) { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; c.member = xcd * 4 + (slot >> 3); c.group = slot & 7; }
   else { c.group = blockIdx.x & 7; c.member = blockIdx.x >> 3; }
   c.head = c.member >> 1; c.half = c.member & 1;
-  c.R = a.B > c.group ? (a.B - c.group + MG_GROUPS - 1) / MG_GROUPS : 0;
-  if (c.R == 0) return;
-  c.hop_base = (gu64*)a.hop + (size_t)c.group * HOP_GROUP;
+  c.member = __builtin_amdgcn_readfirstlane(c.member); c.group = __builtin_amdgcn_readfirstlane(c.group);
+  c.head = c.member >> 1; c.half = c.member & 1;
+  c.Rtot = a.B > c.group ? (a.B - c.group + MG_GROUPS - 1) / MG_GROUPS : 0;     // rows of this group: batch rows group, group + 8, ...
+  if (c.Rtot == 0) return;
+  set_quad(c, 0);
+  c.hop_base = (gu64*)a.hop + (size_t)c.group * HOP_GROUP_ALL;
   c.hop = c.hop_base;
   c.ring = a.ring > 0 ? a.ring : 1;
   c.nlayer = a.L + 1;
@@ -1136,21 +1253,21 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   c.hint_pipe = (a.hint_mask >> 4) & 1;
   c.hint_stride = 1 << ((a.hint_mask >> 13) & 7);
   c.hint_one = (a.hint_mask >> 6) & 1;
-  const int lane = c.lane, R = c.R;
+  const int lane = c.lane, Rtot = c.Rtot;
   const StepParams sp = *a.sp;
 
   // ---- init: zero the activation images, load the row state, build the samplers' seen-map ----
   for (int i = tid; i < L_RED / 4; i += MG_THREADS) ((unsigned*)smem)[i] = 0u;
   for (int i = tid; i < (L_TOTAL - L_KV) / 4; i += MG_THREADS) ((unsigned*)(smem + L_KV))[i] = 0u;   // attention_part relies on finite image cells
-  if (tid < 16) ((int*)(smem + L_ST))[tid] = 0;
+  if (tid < 3 * ST_N + 16) ((int*)(smem + L_ST))[tid] = 0;
   __syncthreads();
-  if (tid < R) {
+  if (tid < Rtot) {                                   // local row tid = 4 * quad + r
     const int b = c.group + MG_GROUPS * tid;
-    st_active(c)[tid] = a.active[b];
-    st_kvlen(c)[tid] = a.kv_len[b];
-    st_step(c)[tid] = a.step_ctr[b];
+    ((int*)(smem + L_ST))[tid] = a.active[b];
+    ((int*)(smem + L_ST))[ST_N + tid] = a.kv_len[b];
+    ((int*)(smem + L_ST))[2 * ST_N + tid] = a.step_ctr[b];
   }
-  if (c.member < R && c.wave == 0) {
+  if (c.member < Rtot && c.wave == 0) {
     unsigned char* seen = smem + L_SEEN;
     for (int v = lane; v < VPAD; v += 64) seen[v] = 0;
     const int b = c.group + MG_GROUPS * c.member;
@@ -1164,8 +1281,8 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   }
   __syncthreads();
   if (group_done(c)) return;
-  if (c.comm) comm_role(a, c, sp);
-  else compute_role(a, c);
+  if (c.comm) comm_role<MULTI>(a, c, sp);
+  else compute_role<MULTI>(a, c);
 }
 
 // census: are 256 workgroups of the engine's footprint co-resident?  Every workgroup arrives on a counter and waits
@@ -1188,7 +1305,7 @@ __global__ __launch_bounds__(MG_THREADS, 1) void mega_census_kernel(unsigned* ws
 bool mega_shape_ok(int dim, int n_head, int ffn, int vocab) { return dim == D && n_head == NH && ffn == FF && vocab >= 64 && vocab <= VPAD; }
 size_t mega_layer_pack_halfs() { return LAYER_HALFS; }
 size_t mega_logits_pack_halfs() { return LOGIT_HALFS; }
-size_t mega_hop_bytes(int ring) { return (size_t)(ring > 0 ? ring : 1) * MG_GROUPS * HOP_GROUP * 8; }
+size_t mega_hop_bytes(int ring) { return (size_t)(ring > 0 ? ring : 1) * MG_GROUPS * HOP_GROUP_ALL * 8; }
 
 // fragment of one KiB-instruction: lane ln holds W[row0 + (ln & 15)][k0 + 8 (ln >> 4) .. +8]
 static void pack_frag(const float* w, int ldw, int row0, int nrows, int k0, _Float16* dst) {
@@ -1244,8 +1361,13 @@ int mega_census(hipStream_t s, unsigned* d_scratch, unsigned* h_pinned) {
 int launch_t2s_mega(const MegaArgs& a, hipStream_t s) {
   // every launch: the attribute belongs to the (function, device) pair, and TTS.set_device may have moved the handle's owner
   // to another GPU of the process since the last launch (mega_census does the same)
-  GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
-  hipLaunchKernelGGL(t2s_mega_kernel, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
+  if (a.B > RMAX * MG_GROUPS) {          // more than one quad per group
+    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
+    hipLaunchKernelGGL(t2s_mega_kernel<true>, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
+  } else {
+    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
+    hipLaunchKernelGGL(t2s_mega_kernel<false>, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
+  }
   GSV_HIP(hipGetLastError());
   return GSV_OK;
 }

@@ -27,7 +27,7 @@ from gsv.AR.models.t2s_model import Text2SemanticDecoder  # noqa: E402
 
 B = int(os.environ.get("PROF_B", "32"))
 cfg = S.T2S_V2_CONFIG
-eng = Text2SemanticDecoder(cfg, device="cuda:0", dtype=torch.float16, max_batch=32, max_seq=320)
+eng = Text2SemanticDecoder(cfg, device="cuda:0", dtype=torch.float16, max_batch=max(32, B), max_seq=320)
 eng.load_state_dict(S.make_t2s_state_dict(cfg, seed=0, suppress_eos=True))
 utt = S.make_utterances(B)
 xs = [torch.tensor(it["all_phones"], device="cuda:0") for it in utt["items"]]
