@@ -1558,6 +1558,7 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
         GSV_HIP(hipMemsetAsync(d_prof, 0, prof_n * 8, s));
         a.prof = d_prof; a.prof_step = getenv("GSV_MEGA_PROF_STEP") ? atoi(getenv("GSV_MEGA_PROF_STEP")) : 5;
         a.prof_layer = getenv("GSV_MEGA_PROF_LAYER") ? atoi(getenv("GSV_MEGA_PROF_LAYER")) : 7;
+        a.prof_quad = getenv("GSV_MEGA_PROF_QUAD") ? atoi(getenv("GSV_MEGA_PROF_QUAD")) : 0;
       }
       GSV_HIP(hipEventRecord(h->mega_ev[0], s));
       GSV_RC(launch_t2s_mega(a, s));

@@ -37,7 +37,7 @@ struct MegaArgs {
   unsigned long long* hop; unsigned* err;
   int B, L, V, nsteps;
   unsigned long long* prof;       // optional [256 workgroups][8 waves][32] s_memtime stamps of one (step, layer); null = off
-  int prof_step, prof_layer;
+  int prof_step, prof_layer, prof_quad;
   int hint_mask;                  // hops that poll one granule per line before the full pass: bit 0 A, 1 B, 2 C, 3 D; bit 4: two polls in flight; bits 8-12: miss threshold; bits 13-15: log2 of the hint line stride
   int map_shared;                 // 1: workgroups reading the same weight slice share an XCD (default), 0: group = XCD
   int ring;                       // hop buffer sets used round-robin over (step, layer); > 1 enables L2-shared payload reads

@@ -678,7 +678,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         set_quad(q, qd);
         const int R = q.R;
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == 0;
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
         MG_STAMP(q, 0);
         // ---- hop A: y of the previous layer (or the step's input embedding) -> LayerNorm -> XS / XRES
         {
@@ -743,7 +743,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         relaunder(q);
         set_quad(q, qd);
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == 0;
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
         if (ra < q.R) {
           u4v qb[2];
           if (sweep_wide<2>(q, q.hop + HOP_B + ra * 256, ep0 + 4 * l + 2, qb, 3u, a.hint_mask & 2)) {
@@ -764,7 +764,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         relaunder(q);
         set_quad(q, qd);
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == 0;
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
         if (ra < q.R) {
           u4v qc[4];
           if (sweep_wide<4>(q, q.hop + HOP_C + ra * 512, ep0 + 4 * l + 3, qc, 4u, a.hint_mask & 4)) ln_row_wide(q, ra, qc, gC, bC);
@@ -781,7 +781,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         relaunder(q);
         set_quad(q, qd);
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == 0;
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
         if (ra < q.R) {
           u4v qd8[8];
           if (sweep_wide<8>(q, q.hop + HOP_D + ra * 1024, ep0 + 4 * l + 4, qd8, 5u, a.hint_mask & 8)) {
@@ -1121,7 +1121,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         set_quad(q, qd);
         const int R = q.R;
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == 0;
+        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
         const f4 p_bias = *(const f4*)(lp + FP_B2 + 16 * q.member + 4 * (q.lane >> 4));
         MG_STAMP(q, 19);
         MG_BAR();                                                          // B1: HS holds the FFN hidden
