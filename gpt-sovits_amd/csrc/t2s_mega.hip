@@ -76,13 +76,13 @@ constexpr int HOP_GROUP = HOP_E + RMAX * VPAD;     // one quad's buffers
 constexpr int HOP_GROUP_ALL = QMAX * HOP_GROUP;    // a group's buffers: quad after quad
 
 // LDS carve (bytes); everything dynamic so the base stays 16-byte aligned
-constexpr int L_RS = 0;                                       // f4 [2][QMAX][64]   residual operands kept per quad (multi-quad launches)
-constexpr int L_XRES = L_RS + 2 * QMAX * 64 * 16;             // fp32 [RMAX][512]   LayerNorm output (residual operand)
-constexpr int L_XS = L_XRES + RMAX * 512 * 4;                 // half [RMAX][XS_LD] LayerNorm output (MFMA operand)
-constexpr int L_AT = L_XS + RMAX * XS_LD * 2;                 // half [RMAX][XS_LD] attention output of all heads
-constexpr int L_HS = L_AT + RMAX * XS_LD * 2;                 // half [RMAX][HS_LD] FFN hidden
-constexpr int L_RED = L_HS + RMAX * HS_LD * 2;                // f4 [24][64] split-K partials
-constexpr int L_QKV = L_RED + 24 * 64 * 16;                   // half [2][3][32] q,k,v of the own rows
+constexpr int L_XRES = 0;                                     // fp32 [RMAX][512]   LayerNorm output (residual operand); one quad per group
+constexpr int L_RS = 0;                                       // f4 [2][QMAX][64]   the same 8 KB in multi-quad launches: residual operands kept per quad
+constexpr int L_XS = L_XRES + RMAX * 512 * 4;                 // half [2][RMAX][XS_LD] LayerNorm output (MFMA operand); second copy: pipelined quads
+constexpr int L_AT = L_XS + 2 * RMAX * XS_LD * 2;             // half [2][RMAX][XS_LD] attention output of all heads
+constexpr int L_HS = L_AT + 2 * RMAX * XS_LD * 2;             // half [2][RMAX][HS_LD] FFN hidden
+constexpr int L_RED = L_HS + 2 * RMAX * HS_LD * 2;            // f4 [24][16] split-K partials: the RMAX valid batch rows of each 16 x 16 tile
+constexpr int L_QKV = L_RED + 24 * 16 * 16;                   // half [2][3][32] q,k,v of the own rows
 constexpr int L_ATT = L_QKV + 2 * 3 * 32 * 2;                 // float [8] m + [8 waves][4 rows of 16 lanes][36] acc,l partials
 constexpr int L_STAGE = L_ATT + 32 + 8 * 4 * 36 * 4;          // 4 x 1 KB: per-wave transposition buffers of the publishers
 constexpr int L_ST = L_STAGE + 4 * 1024;                      // int: active[QMAX * RMAX], kvlen[..], step[..], abort, -, barrier counter, flag
@@ -419,6 +419,9 @@ __device__ __forceinline__ void ln_row_wide(const Ctx& c, int row, const u4v (&v
 
 // compute waves: NT tiles x 4 k-steps of this wave's 128-wide K chunk `kc` against the activation image `act`
 // (half [RMAX][ld]); partial tiles go to red[(slot0 + t)][lane]
+// a parked tile: lanes with (lane & 15) < RMAX, i.e. 4 row-lanes x 4 column groups = 16 f4 per tile
+__device__ __forceinline__ int red_idx(int slot, int lane) { return slot * 16 + (lane >> 4) * 4 + (lane & 15); }
+
 template <int NT>
 __device__ __forceinline__ void gemm_chunk(const Ctx& c, const h8 (&w)[NT * 4], const _Float16* act, int ld, int kc, int slot0) {
   const int rowl = c.lane & 15, kg = c.lane >> 4;
@@ -432,7 +435,7 @@ __device__ __forceinline__ void gemm_chunk(const Ctx& c, const h8 (&w)[NT * 4], 
     f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[t * 4 + ks], b[ks], acc, 0, 0, 0);
-    red[(slot0 + t) * 64 + c.lane] = acc;
+    if (rowl < RMAX) red[red_idx(slot0 + t, c.lane)] = acc;     // only the tile's first RMAX batch rows hold rows of the quad
   }
 }
 
@@ -643,6 +646,84 @@ __device__ __forceinline__ void kv_stage_store(const Ctx& q, int qd, int extra, 
   }
 }
 
+// sampling of the group's local row `member` by wave 0 of that member (reference utils.py:140-199, t2s_model.py:706-769): after the
+// logits of every quad have been published, so that the samplers of all quads work side by side.  A MACRO, not a function: as an
+// (inlined) function taking the context by reference the same text cost > 1000 spilled VGPRs in every kernel variant.
+// Expects a, q, sp, s, ep0, EPS, seen in scope.
+#define MG_RUN_SAMPLER() do { \
+  const int V = a.V, EOS = a.V - 1; \
+  const unsigned epE = ep0 + 4 * a.L + 2; \
+    relaunder(q); \
+    set_quad(q, q.member / RMAX); \
+    q.hop = hop_slot(q, s, a.L); \
+    const int r = q.member % RMAX, b = batch_row(q, r); \
+    const unsigned epN = ep0 + (unsigned)EPS + 1; \
+    const int was_active = st_active(q)[r]; \
+    int now_active = 0; \
+    float x0[8]; \
+  _Pragma("unroll") \
+    for (int k = 0; k < 8; ++k) x0[k] = 0.f; \
+ \
+ \
+    unsigned lv[17]; \
+    const bool ok = sweep<17>(q, q.hop + HOP_E + r * VPAD, V, epE, lv, 7u); \
+    if (was_active && ok) { \
+      const int step = st_step(q)[r]; \
+      const int Veff = step < sp.eos_mask_steps ? V - 1 : V; \
+      float x[17]; \
+  _Pragma("unroll") \
+      for (int i = 0; i < 17; ++i) { \
+        const int v = q.lane + 64 * i; \
+        if (v < V) a.logits_out[(size_t)b * V + v] = __uint_as_float(lv[i]); \
+        x[i] = v < Veff ? __uint_as_float(lv[i]) : -INFINITY; \
+        if (sp.rep_penalty != 1.0f && v < Veff && seen[v]) x[i] = x[i] < 0.f ? x[i] * sp.rep_penalty : x[i] / sp.rep_penalty; \
+      } \
+      const float* nrow = nullptr; \
+      if (sp.noise) nrow = sp.noise + ((size_t)step * sp.noise_rows + (sp.noise_rows > 1 ? b : 0)) * V; \
+      int smp, amx; \
+      sample_core<17>(x, Veff, sp.top_k, sp.top_p, sp.temperature, nrow, sp.seed, b, step, &smp, &amx); \
+      if (sp.dump) { \
+  _Pragma("unroll") \
+        for (int i = 0; i < 17; ++i) { \
+          const int v = q.lane + 64 * i; \
+          if (v < V) sp.dump[((size_t)step * a.B + b) * V + v] = __uint_as_float(lv[i]); \
+        } \
+      } \
+      if (sp.drawn && q.lane == 0) { int* dr = sp.drawn + ((size_t)step * a.B + b) * 2; dr[0] = smp; dr[1] = amx; } \
+      if (sp.force) { smp = sp.force[(size_t)b * sp.max_steps + step]; amx = smp; } \
+      const bool fin = smp == EOS || amx == EOS; \
+      const bool early = (sp.early_stop_num != -1 && (step + 1) > sp.early_stop_num) || step >= sp.max_steps - 1; \
+      const int prev_len = sp.P + step; \
+      if (q.lane == 0) { \
+        if (prev_len < a.ycap) a.ytok[(size_t)b * a.ycap + prev_len] = smp; \
+        if (smp >= 0 && smp < VPAD) seen[smp] = 1; \
+        if (fin || early) { \
+          a.active[b] = 0; \
+          sp.out_len[b] = step; \
+          atomicSub(a.n_active, 1); \
+        } else { \
+          sp.out_tokens[(size_t)b * sp.max_steps + step] = smp; \
+          a.kv_len[b] = st_kvlen(q)[r] + 1; \
+        } \
+        a.step_ctr[b] = step + 1; \
+      } \
+      if (!(fin || early)) { \
+        now_active = 1; \
+        const int tok = min(max(smp, 0), V - 1); \
+        const float* e = a.e_audio + (size_t)tok * D; \
+        const float* p = a.pe + (size_t)(sp.P + step) * D; \
+  _Pragma("unroll") \
+        for (int k = 0; k < 8; ++k) x0[k] = e[k * 64 + q.lane] + a.alpha_a * p[k * 64 + q.lane]; \
+      } \
+    } \
+    if (ok && s + 1 < a.nsteps) { \
+      gu64* hn = hop_slot(q, s + 1, 0); \
+  _Pragma("unroll") \
+      for (int k = 0; k < 8; ++k) gstore(hn + HOP_A + r * 512 + k * 64 + q.lane, epN, __float_as_uint(x0[k])); \
+      if (q.lane == 0) gstore(hn + HOP_ST + r, epN, (unsigned)now_active); \
+    } \
+} while (0)
+
 // MULTI = false: the group has ONE quad (B <= 32), the quad loops below run once with qd = 0 and fold away.
 // MULTI = true (32 < B <= 128): a group serves up to QMAX quads.  Every phase of a layer is run for quad 0, 1, ... in turn with
 // the weights the compute waves already hold; each quad has its own hop buffers, so while a member works on quad q the other
@@ -813,79 +894,8 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
       if (*st_abort(q)) return;
       MG_BAR();                                                            // B2
     }
-    // ---- sampling of the group's local row `member` (reference utils.py:140-199, t2s_model.py:706-769): after the logits of
-    // every quad have been published, so that the samplers of all quads work side by side
-    if (sampler) {
-      relaunder(q);
-      set_quad(q, q.member / RMAX);
-      q.hop = hop_slot(q, s, a.L);
-      const int r = q.member % RMAX, b = batch_row(q, r);
-      const unsigned epN = ep0 + (unsigned)EPS + 1;                      // hop A of the next step's layer 0
-      const int was_active = st_active(q)[r];
-      int now_active = 0;
-      float x0[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) x0[k] = 0.f;
-      // The logits row is consumed even when the row has finished: its arrival proves that every member has read this
-      // step's HOP_A (the last layer's y2) -- only then may the next step's embedding overwrite that buffer.
-      unsigned lv[17];
-      const bool ok = sweep<17>(q, q.hop + HOP_E + r * VPAD, V, epE, lv, 7u);
-      if (was_active && ok) {
-        const int step = st_step(q)[r];
-        const int Veff = step < sp.eos_mask_steps ? V - 1 : V;
-        float x[17];
-#pragma unroll
-        for (int i = 0; i < 17; ++i) {
-          const int v = q.lane + 64 * i;
-          if (v < V) a.logits_out[(size_t)b * V + v] = __uint_as_float(lv[i]);
-          x[i] = v < Veff ? __uint_as_float(lv[i]) : -INFINITY;
-          if (sp.rep_penalty != 1.0f && v < Veff && seen[v]) x[i] = x[i] < 0.f ? x[i] * sp.rep_penalty : x[i] / sp.rep_penalty;
-        }
-        const float* nrow = nullptr;
-        if (sp.noise) nrow = sp.noise + ((size_t)step * sp.noise_rows + (sp.noise_rows > 1 ? b : 0)) * V;
-        int smp, amx;
-        sample_core<17>(x, Veff, sp.top_k, sp.top_p, sp.temperature, nrow, sp.seed, b, step, &smp, &amx);
-        if (sp.dump) {                                       // parity hooks (gsv_t2s_set_debug), null in production
-#pragma unroll
-          for (int i = 0; i < 17; ++i) {
-            const int v = q.lane + 64 * i;
-            if (v < V) sp.dump[((size_t)step * a.B + b) * V + v] = __uint_as_float(lv[i]);
-          }
-        }
-        if (sp.drawn && q.lane == 0) { int* dr = sp.drawn + ((size_t)step * a.B + b) * 2; dr[0] = smp; dr[1] = amx; }
-        if (sp.force) { smp = sp.force[(size_t)b * sp.max_steps + step]; amx = smp; }
-        const bool fin = smp == EOS || amx == EOS;
-        const bool early = (sp.early_stop_num != -1 && (step + 1) > sp.early_stop_num) || step >= sp.max_steps - 1;
-        const int prev_len = sp.P + step;
-        if (q.lane == 0) {
-          if (prev_len < a.ycap) a.ytok[(size_t)b * a.ycap + prev_len] = smp;
-          if (smp >= 0 && smp < VPAD) seen[smp] = 1;
-          if (fin || early) {
-            a.active[b] = 0;
-            sp.out_len[b] = step;
-            atomicSub(a.n_active, 1);
-          } else {
-            sp.out_tokens[(size_t)b * sp.max_steps + step] = smp;
-            a.kv_len[b] = st_kvlen(q)[r] + 1;
-          }
-          a.step_ctr[b] = step + 1;
-        }
-        if (!(fin || early)) {
-          now_active = 1;
-          const int tok = min(max(smp, 0), V - 1);
-          const float* e = a.e_audio + (size_t)tok * D;
-          const float* p = a.pe + (size_t)(sp.P + step) * D;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) x0[k] = e[k * 64 + q.lane] + a.alpha_a * p[k * 64 + q.lane];
-        }
-      }
-      if (ok && s + 1 < a.nsteps) {
-        gu64* hn = hop_slot(q, s + 1, 0);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) gstore(hn + HOP_A + r * 512 + k * 64 + q.lane, epN, __float_as_uint(x0[k]));
-        if (q.lane == 0) gstore(hn + HOP_ST + r, epN, (unsigned)now_active);
-      }
-    }
+    // ---- sampling (see run_sampler)
+    if (sampler) MG_RUN_SAMPLER();
   }
 }
 
@@ -910,7 +920,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
   // residual operands of the out-projection (LN(y) of hop A) and of FFN2 (LN1(y1) of hop C) for the reducing wave's lanes.
   // One quad: read from XRES when needed.  Several quads: XRES is overwritten by the next quad's LayerNorm before the phase
   // that needs it comes round, so the member's 16 columns of every row are parked per quad (f4 per lane, 1 KB per quad).
-  auto rs_slot = [&](int which, int qd) { return (f4*)(smem + L_RS) + (which * QMAX + qd) * 64 + q.lane; };
+  auto rs_slot = [&](int which, int qd) { return (f4*)(smem + L_HS + RMAX * HS_LD * 2) + (which * QMAX + qd) * 64 + q.lane; };   // (the second HS copy: unused by these roles)
   // K/V arena append of this step's k, v (own rows), from the LDS copy the attention used
   auto arena_append = [&](int l) {
     const int ro = q.lane >> 4, which = (q.lane >> 3) & 1, e = 4 * (q.lane & 7), r = 2 * ro + q.half;
@@ -974,8 +984,8 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
           const int ro = q.cw / 2, r = 2 * ro + q.half;
           if (q.lane < 24 && r < R) {
             const int tile = rj_which * 2 + (rj_e >> 4), ln = r + 16 * ((rj_e & 15) >> 2);
-            const f4 v0 = red[(0 * 6 + tile) * 64 + ln], v1 = red[(1 * 6 + tile) * 64 + ln], v2 = red[(2 * 6 + tile) * 64 + ln],
-                     v3 = red[(3 * 6 + tile) * 64 + ln];
+            const f4 v0 = red[red_idx(0 * 6 + tile, ln)], v1 = red[red_idx(1 * 6 + tile, ln)], v2 = red[red_idx(2 * 6 + tile, ln)],
+                     v3 = red[red_idx(3 * 6 + tile, ln)];
             f4 v = v0;
             v += v1; v += v2; v += v3;
             v += p1_bias;
@@ -1047,7 +1057,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
           const f4* red = (const f4*)(smem + L_RED);
           const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
           if (r < R) {
-            const f4 v0 = red[q.lane], v1 = red[64 + q.lane], v2 = red[128 + q.lane], v3 = red[192 + q.lane];
+            const f4 v0 = red[red_idx(0, q.lane)], v1 = red[red_idx(1, q.lane)], v2 = red[red_idx(2, q.lane)], v3 = red[red_idx(3, q.lane)];
             const f4 xr = MULTI ? *rs_slot(0, qd) : *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
             f4 v = v0;
             v += v1; v += v2; v += v3;
@@ -1101,8 +1111,8 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
               const int tile = 2 * q.cw + tt;
-              const f4 v0 = red[(0 * 4 + tile) * 64 + q.lane], v1 = red[(1 * 4 + tile) * 64 + q.lane],
-                       v2 = red[(2 * 4 + tile) * 64 + q.lane], v3 = red[(3 * 4 + tile) * 64 + q.lane];
+              const f4 v0 = red[red_idx(0 * 4 + tile, q.lane)], v1 = red[red_idx(1 * 4 + tile, q.lane)],
+                       v2 = red[red_idx(2 * 4 + tile, q.lane)], v3 = red[red_idx(3 * 4 + tile, q.lane)];
               f4 v = v0;
               v += v1; v += v2; v += v3;
               v += tt == 0 ? p_bias : p_bias2;
@@ -1143,7 +1153,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
             for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wD[cc * 4 + ks], *(const h8*)(bp + 32 * ks), acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);       // keep the 16 operand reads from being hoisted in front of the first MFMA
           }
-          red[q.cw * 64 + q.lane] = acc;
+          if (rowl < RMAX) red[red_idx(q.cw, q.lane)] = acc;
         }
         // second half of the next P1 slice: this quad's FFN2 is done, and the request is still in front of the publish
         wload(wA1, p1_src(l + 1 < a.L ? l + 1 : 0) + (size_t)(WI_P1 / 2) * 64);
@@ -1154,7 +1164,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
           const f4* red = (const f4*)(smem + L_RED);
           const int r = q.lane & 15, n0 = 16 * q.member + 4 * (q.lane >> 4);
           if (r < R) {
-            const f4 v0 = red[q.lane], v1 = red[64 + q.lane], v2 = red[128 + q.lane], v3 = red[192 + q.lane];
+            const f4 v0 = red[red_idx(0, q.lane)], v1 = red[red_idx(1, q.lane)], v2 = red[red_idx(2, q.lane)], v3 = red[red_idx(3, q.lane)];
             const f4 xr = MULTI ? *rs_slot(1, qd) : *(const f4*)((const float*)(smem + L_XRES) + r * D + n0);
             f4 v = v0;
             v += v1; v += v2; v += v3;
@@ -1190,8 +1200,8 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         const int tile = t == 0 ? q.member : (t == 1 ? q.member + 32 : 64);
         float* stage = (float*)(smem + L_STAGE) + q.cw * 256;
         if (r < R) {
-          f4 v = red[(0 * 3 + t) * 64 + q.lane];
-          v += red[(1 * 3 + t) * 64 + q.lane]; v += red[(2 * 3 + t) * 64 + q.lane]; v += red[(3 * 3 + t) * 64 + q.lane];
+          f4 v = red[red_idx(0 * 3 + t, q.lane)];
+          v += red[red_idx(1 * 3 + t, q.lane)]; v += red[red_idx(2 * 3 + t, q.lane)]; v += red[red_idx(3 * 3 + t, q.lane)];
           *(f4*)(stage + r * 16 + 4 * (q.lane >> 4)) = v;
         }
         if (q.lane < R * 16 && (t < 2 || q.member == 0) && 16 * tile + (q.lane & 15) < V)
@@ -1203,7 +1213,470 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
   }
 }
 
-template <bool MULTI>
+// ---------------------------------------------------------------------------------------------------------------
+// Pipelined quads (32 < B <= 128).  The sequential-quad roles above (MULTI = true) wait out every quad's sweep round trip
+// (~1.1 us even when the data arrived long ago) in front of its GEMM: a GEMM-phase slot costs 1.8-2.7 us, a layer 44 us
+// for four quads (in-kernel stamps, gpurun_out r3_prof128_*).  Here the comm waves sweep quad i + 1's hop into the SECOND
+// copy of the operand image while the compute waves multiply, reduce and publish quad i -- one workgroup barrier per slot:
+//     comm:    sweep(0) | B | sweep(1)              | B | sweep(2)              | B | ...
+//     compute:          | B | gemm(0) cb reduce(0)  | B | gemm(1) cb reduce(1)  | B | ...
+// and P1 (QKV + attention) keeps two barriers per slot: B_a (the previous quad's attention has released the K/V image,
+// LN(hop A) of this quad is in its XS copy) and B_b (the image of this quad is stored; the QKV partials are parked).
+// The member's 16 residual columns of every row are parked per quad by the LayerNorm itself (no XRES image).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f4* rs_at(unsigned char* smem, int which, int qd, int lane) { return (f4*)(smem + L_RS) + (which * QMAX + qd) * 64 + lane; }
+
+// LayerNorm of one row delivered by sweep_wide<4> -> XS copy `buf` (MFMA operand) + the member's residual columns -> rs[which][qd]
+__device__ __forceinline__ void ln_row_pipe(const Ctx& c, int row, int buf, int which, const u4v (&v)[4], const float* gm, const float* bt) {
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { x[2 * j] = __uint_as_float(v[j][0]); x[2 * j + 1] = __uint_as_float(v[j][2]); }
+  if (gm) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += x[k];
+    const float mean = wave_sum_dpp(s) * (1.f / D);
+    float qq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float dl = x[k] - mean; qq += dl * dl; }
+    const float rstd = rsqrtf(wave_sum_dpp(qq) * (1.f / D) + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = (x[k] - mean) * rstd * gm[k] + bt[k];
+  }
+  _Float16* xs = (_Float16*)(c.smem + L_XS) + (buf * RMAX + row) * XS_LD + 2 * c.lane;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *(h2*)(xs + j * 128) = (h2){(_Float16)x[2 * j], (_Float16)x[2 * j + 1]};
+  // columns [16 member, +16) of this row: chunk j = member / 8, lanes 8 (member % 8) .. + 7, two elements each; the reducing
+  // wave's lane r + 16 g holds columns 4 g .. 4 g + 3 of row r
+  const int jm = c.member >> 3, m0 = 8 * (c.member & 7), dm = c.lane - m0;
+  const float e0 = jm == 0 ? x[0] : jm == 1 ? x[2] : jm == 2 ? x[4] : x[6];
+  const float e1 = jm == 0 ? x[1] : jm == 1 ? x[3] : jm == 2 ? x[5] : x[7];
+  if (dm >= 0 && dm < 8)
+    *(f2*)((float*)rs_at(c.smem, which, c.qd, row + 16 * (dm >> 1)) + 2 * (dm & 1)) = (f2){e0, e1};
+}
+
+__device__ __forceinline__ void comm_role_pipe(const MegaArgs& a, const Ctx& c0, const StepParams& sp) {
+  Ctx q = c0;
+  unsigned char* smem = c0.smem;
+  const int Rtot = c0.Rtot;
+  const int nq = (Rtot + RMAX - 1) / RMAX;
+  const bool sampler = c0.member < Rtot && c0.cw == 0;
+  const int EPS = 4 * a.L + 2;
+  unsigned char* seen = smem + L_SEEN;
+  KvStage kvs;
+  set_quad(q, 0);
+  kv_stage_load(a, q, 0, 0, 0, kvs);                 // image of (layer 0, quad 0): stored by the first P1 slot like every other
+  float gC[8], bC[8], gA[8], bA[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gC[k] = bC[k] = gA[k] = bA[k] = 0.f;
+  const int ra = c0.cw;                              // this wave's row of every quad
+  for (int s = 0; s < a.nsteps; ++s) {
+    const unsigned ep0 = a.ep_base + (unsigned)s * (unsigned)EPS;
+    for (int l = 0; l < a.L; ++l) {
+      const float* lp = a.fpack + (size_t)l * FP_LAYER;
+      // hop A of quad qd -> LayerNorm -> XS copy qd & 1 (+ the residual columns of the out-projection)
+      auto sweep_a = [&](int qd) {
+        relaunder(q);
+        set_quad(q, qd);
+        q.hop = hop_slot(q, s, l);
+        if (ra < q.R) {
+          u4v qa[4];
+          bool ok = true;
+          if (s == 0 && l == 0) {
+            const float* ya = a.ybuf + (size_t)batch_row(q, ra) * D + 2 * q.lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const f2 y2 = *(const f2*)(ya + j * 128); qa[j] = (u4v){__float_as_uint(y2[0]), 0u, __float_as_uint(y2[1]), 0u}; }
+          } else {
+            ok = sweep_wide<4>(q, q.hop + HOP_A + ra * 512, ep0 + 4 * l + 1, qa, 1u, a.hint_mask & 1);
+          }
+          if (ok) ln_row_pipe(q, ra, qd & 1, 0, qa, l > 0 ? gA : nullptr, bA);
+        }
+      };
+      // ================= P1
+      q.prof_on = false;
+      sweep_a(0);
+      if (l == 0 && s > 0 && q.cw == 0) {
+        // row state published by the samplers with the embedding, every quad's rows (see comm_role)
+        for (int q2 = 0; q2 < nq; ++q2) {
+          Ctx t = q;
+          set_quad(t, q2);
+          unsigned sv[1];
+          if (sweep<1>(t, hop_slot(t, s, l) + HOP_ST, t.R, ep0 + 1, sv, 2u) && t.lane < t.R) {
+            const int was = st_active(t)[t.lane], now = (int)(sv[0] & 1u);
+            if (was) { st_step(t)[t.lane] += 1; if (now) st_kvlen(t)[t.lane] += 1; }
+            st_active(t)[t.lane] = now;
+          }
+        }
+      }
+      for (int qd = 0; qd < nq; ++qd) {
+        MG_BAR();                                                          // B_a
+        if (*st_abort(q)) return;
+        if (l == 0 && s > 0 && qd == 0 && group_done(q)) return;
+        relaunder(q);
+        // the image of THIS slot's quad (requested one slot ago) -> LDS.  At (l = 0, qd = 0) of a step after the first the rows'
+        // state has just advanced: the image was requested with extra = 1 at the end of the previous step, the store uses the
+        // advanced state with extra = 0 -- the same positions
+        kv_stage_store(q, qd, 0, kvs);
+        MG_BAR();                                                          // B_b
+        if (*st_abort(q)) return;
+        // the NEXT slot's image (the compute waves run the reduce and the attention meanwhile)
+        const bool kv_same = qd + 1 < nq;
+        const int kv_nq = kv_same ? qd + 1 : 0;
+        const int kv_nl = kv_same ? l : (l + 1 < a.L ? l + 1 : 0), kv_extra = (kv_same || l + 1 < a.L) ? 0 : 1;
+        if (kv_same || l + 1 < a.L || s + 1 < a.nsteps) kv_stage_load(a, q, kv_nl, kv_nq, kv_extra, kvs);
+        if (kv_same) sweep_a(qd + 1);
+        else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int el = (k >> 1) * 128 + 2 * q.lane + (k & 1);
+            gC[k] = lp[FP_N1W + el]; bC[k] = lp[FP_N1B + el];
+            gA[k] = lp[FP_N2W + el]; bA[k] = lp[FP_N2B + el];
+          }
+        }
+      }
+      // ================= P2: hop B -> AT copies
+      auto sweep_b = [&](int qd) {
+        relaunder(q);
+        set_quad(q, qd);
+        q.hop = hop_slot(q, s, l);
+        if (ra < q.R) {
+          u4v qb[2];
+          if (sweep_wide<2>(q, q.hop + HOP_B + ra * 256, ep0 + 4 * l + 2, qb, 3u, a.hint_mask & 2)) {
+            unsigned* at = (unsigned*)(smem + L_AT) + ((qd & 1) * RMAX + ra) * (XS_LD / 2) + 2 * q.lane;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *(u2v*)(at + j * 128) = (u2v){qb[j][0], qb[j][2]};
+          }
+        }
+      };
+      sweep_b(0);
+      for (int qd = 0; qd < nq; ++qd) {
+        MG_BAR();
+        if (*st_abort(q)) return;
+        if (qd + 1 < nq) sweep_b(qd + 1);
+      }
+      // ================= P3: hop C -> LayerNorm1 -> XS copies (+ the residual columns of FFN2)
+      auto sweep_c = [&](int qd) {
+        relaunder(q);
+        set_quad(q, qd);
+        q.hop = hop_slot(q, s, l);
+        if (ra < q.R) {
+          u4v qc[4];
+          if (sweep_wide<4>(q, q.hop + HOP_C + ra * 512, ep0 + 4 * l + 3, qc, 4u, a.hint_mask & 4)) ln_row_pipe(q, ra, qd & 1, 1, qc, gC, bC);
+        }
+      };
+      sweep_c(0);                       // no barrier between the phases: this sweep overlaps the last out-projection slot
+      for (int qd = 0; qd < nq; ++qd) {
+        MG_BAR();
+        if (*st_abort(q)) return;
+        if (qd + 1 < nq) sweep_c(qd + 1);
+      }
+      // ================= P4: hop D -> HS copies
+      auto sweep_d = [&](int qd) {
+        relaunder(q);
+        set_quad(q, qd);
+        q.hop = hop_slot(q, s, l);
+        if (ra < q.R) {
+          u4v qd8[8];
+          if (sweep_wide<8>(q, q.hop + HOP_D + ra * 1024, ep0 + 4 * l + 4, qd8, 5u, a.hint_mask & 8)) {
+            unsigned* hs = (unsigned*)(smem + L_HS) + ((qd & 1) * RMAX + ra) * (HS_LD / 2) + 2 * q.lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *(u2v*)(hs + j * 128) = (u2v){qd8[j][0], qd8[j][2]};
+          }
+        }
+      };
+      sweep_d(0);
+      for (int qd = 0; qd < nq; ++qd) {
+        MG_BAR();
+        if (*st_abort(q)) return;
+        if (qd + 1 < nq) sweep_d(qd + 1);
+      }
+    }
+    // ---- tail: hop A' -> LayerNorm2 of the last layer -> XS copies; logits by the compute waves
+    auto sweep_t = [&](int qd) {
+      relaunder(q);
+      set_quad(q, qd);
+      q.hop = hop_slot(q, s, a.L);
+      if (ra < q.R) {
+        u4v qa[4];
+        if (sweep_wide<4>(q, q.hop + HOP_A + ra * 512, ep0 + 4 * a.L + 1, qa, 6u, a.hint_mask & 1)) ln_row_pipe(q, ra, qd & 1, 0, qa, gA, bA);
+      }
+    };
+    sweep_t(0);
+    for (int qd = 0; qd < nq; ++qd) {
+      MG_BAR();
+      if (*st_abort(q)) return;
+      if (qd + 1 < nq) sweep_t(qd + 1);
+    }
+    MG_BAR();                // end of the step's GEMMs: the last logits GEMM has read its XS copy (the next step's first sweep rewrites copy 0)
+    if (*st_abort(q)) return;
+    if (sampler) MG_RUN_SAMPLER();
+  }
+}
+
+__device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& c0) {
+  Ctx q = c0;
+  unsigned char* smem = c0.smem;
+  const int Rtot = c0.Rtot;
+  const int nq = (Rtot + RMAX - 1) / RMAX;
+  const int V = a.V;
+  const int EPS = 4 * a.L + 2;
+  auto kv_row_base = [&](int layer, int which, int r) -> const _Float16* {
+    const int b = batch_row(q, r);
+    return a.kv + ((size_t)(layer * 2 + which)) * a.kv_layer_stride + ((size_t)b * NH + q.head) * (size_t)a.smax * HD;
+  };
+  const h8* wp = a.wpack;
+  auto p1_src = [&](int layer) { return wp + ((size_t)layer * LAYER_HALFS + ((size_t)q.head * 4 + q.cw) * WI_P1 * 512) / 8 + q.lane; };
+  auto pm_src = [&](int layer, int off) {
+    return wp + ((size_t)layer * LAYER_HALFS + P1_HALFS + (((size_t)q.member * 4 + q.cw) * (WI_P2 + WI_P3 + WI_P4) + off) * 512) / 8 + q.lane;
+  };
+  h8 wA0[WI_P1 / 2], wA1[WI_P1 / 2], wB[WI_P2], wC[WI_P3], wD[WI_P4];
+  int cgen = 0;
+  wload(wA0, p1_src(0));
+  wload(wA1, p1_src(0) + (size_t)(WI_P1 / 2) * 64);
+  for (int s = 0; s < a.nsteps; ++s) {
+    const unsigned ep0 = a.ep_base + (unsigned)s * (unsigned)EPS;
+    for (int l = 0; l < a.L; ++l) {
+      const float* lp = a.fpack + (size_t)l * FP_LAYER;
+      // ================= P1.  The first slot's barrier and the next phase's weight request stand in FRONT of the quad loop: a
+      // request inside the loop is either conditional (`if (qd == 0)`: a conditional definition keeps the register array's old
+      // contents alive around the whole loop, ~100 spilled VGPRs) or repeated per quad -- and the weight loads are
+      // non-temporal, so the repeats miss L2 and every quad streamed the layer's slice again from the memory side: 6 GB per
+      // step at B = 128, no faster than the sequential quads (1.07 ms per step both)
+      MG_BAR();                                                            // B_a of quad 0
+      if (*st_abort(q)) return;
+      if (l == 0 && s > 0 && group_done(q)) return;
+      relaunder(q);
+      wload(wB, pm_src(l, 0));
+      for (int qd = 0; qd < nq; ++qd) {
+        if (qd > 0) {
+          MG_BAR();                                                        // B_a: XS copy qd & 1 holds LN(y); the image is free
+          if (*st_abort(q)) return;
+        }
+        relaunder(q);
+        set_quad(q, qd);
+        const int R = q.R;
+        q.hop = hop_slot(q, s, l);
+        q.prof_on = false;
+        const int rj_which = (q.lane >> 3) % 3, rj_e = 4 * (q.lane & 7);
+        const f4 p1_bias = q.lane < 24 ? *(const f4*)(lp + FP_QKVB + rj_which * D + q.head * HD + rj_e) : (f4){0.f, 0.f, 0.f, 0.f};
+        const _Float16* xs = (const _Float16*)(smem + L_XS) + (qd & 1) * RMAX * XS_LD;
+        gemm_chunk<3>(q, wA0, xs, XS_LD, q.cw, q.cw * 6);
+        gemm_chunk<3>(q, wA1, xs, XS_LD, q.cw, q.cw * 6 + 3);
+        MG_BAR();                                                          // B_b: partials parked, this quad's K/V image stored
+        if (*st_abort(q)) return;
+        {
+          const f4* red = (const f4*)(smem + L_RED);
+          _Float16* qkv_s = (_Float16*)(smem + L_QKV);
+          const int ro = q.cw / 2, r = 2 * ro + q.half;
+          if (q.lane < 24 && r < R) {
+            const int tile = rj_which * 2 + (rj_e >> 4), ln = r + 16 * ((rj_e & 15) >> 2);
+            const f4 v0 = red[red_idx(0 * 6 + tile, ln)], v1 = red[red_idx(1 * 6 + tile, ln)], v2 = red[red_idx(2 * 6 + tile, ln)],
+                     v3 = red[red_idx(3 * 6 + tile, ln)];
+            f4 v = v0;
+            v += v1; v += v2; v += v3;
+            v += p1_bias;
+            *(h4*)(qkv_s + (ro * 3 + rj_which) * HD + rj_e) = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+          }
+          asm volatile("" ::: "memory");
+        }
+        attention_part<2>(a, q, l, q.cw);
+        compute_barrier(q, cgen);                                          // the partials of a row's two waves meet (compute waves only)
+        if (*st_abort(q)) return;
+        if (q.cw == 0) {
+          const float* s_m = (const float*)(smem + L_ATT);
+          const float* s_acc = s_m + 8;
+          const int ro = q.lane >> 5, e = q.lane & 31, r = 2 * ro + q.half;
+          float M = -INFINITY;
+#pragma unroll
+          for (int w = 0; w < 2; ++w) M = fmaxf(M, s_m[2 * ro + w]);
+          float o = 0.f;
+          if (M != -INFINITY) {
+            float Lsum = 0.f, num = 0.f;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+              const float mw = s_m[2 * ro + w];
+              const float ew = mw == -INFINITY ? 0.f : __expf(mw - M);
+              const float* pa = s_acc + (2 * ro + w) * 4 * 36;
+              Lsum += ((pa[32] + pa[36 + 32]) + (pa[72 + 32] + pa[108 + 32])) * ew;
+              num += ((pa[e] + pa[36 + e]) + (pa[72 + e] + pa[108 + e])) * ew;
+            }
+            o = num / Lsum;
+          }
+          const float o2 = dpp_f<DPP_QUAD_XOR1>(o);
+          if (r < R && !(e & 1)) gstore(q.hop + HOP_B + r * 256 + (q.head * HD + e) / 2, ep0 + 4 * l + 2, pack_h2(o, o2));
+        }
+        if (q.cw == 1 && q.lane < 32) {                                    // K/V arena append of this step's k, v (see compute_role)
+          const int ro = q.lane >> 4, which = (q.lane >> 3) & 1, e = 4 * (q.lane & 7), r = 2 * ro + q.half;
+          if (r < R && st_active(q)[r]) {
+            const int pos = st_kvlen(q)[r];
+            if (pos < a.smax)
+              *(h4*)(const_cast<_Float16*>(kv_row_base(l, which, r)) + (size_t)pos * HD + e) =
+                  *(const h4*)((const _Float16*)(smem + L_QKV) + (ro * 3 + 1 + which) * HD + e);
+          }
+        }
+      }
+      // ================= P2: out-projection
+      MG_BAR();                                                            // AT copy 0 holds quad 0's attention output
+      if (*st_abort(q)) return;
+      relaunder(q);
+      wload(wC, pm_src(l, WI_P2));
+      for (int qd = 0; qd < nq; ++qd) {
+        if (qd > 0) {
+          MG_BAR();                                                        // AT copy qd & 1 holds the attention output
+          if (*st_abort(q)) return;
+        }
+        relaunder(q);
+        set_quad(q, qd);
+        const int R = q.R;
+        q.hop = hop_slot(q, s, l);
+        const f4 p_bias = *(const f4*)(lp + FP_OUTB + 16 * q.member + 4 * (q.lane >> 4));
+        gemm_chunk<1>(q, wB, (const _Float16*)(smem + L_AT) + (qd & 1) * RMAX * XS_LD, XS_LD, q.cw, q.cw);
+        compute_barrier(q, cgen);
+        if (*st_abort(q)) return;
+        if (q.cw == 0) {
+          const f4* red = (const f4*)(smem + L_RED);
+          const int r = q.lane & 15;
+          if (r < R) {
+            const f4 v0 = red[red_idx(0, q.lane)], v1 = red[red_idx(1, q.lane)], v2 = red[red_idx(2, q.lane)], v3 = red[red_idx(3, q.lane)];
+            f4 v = v0;
+            v += v1; v += v2; v += v3;
+            v += p_bias;
+            v += *rs_at(smem, 0, qd, q.lane);
+            *(f4*)((float*)(smem + L_STAGE) + r * 16 + 4 * (q.lane >> 4)) = v;
+          }
+          const bool stall = a.test_stall && q.member == a.test_stall - 1 && q.group == 0 && s == 2 && l == 3 && qd == 0;
+          if (q.lane < R * 16 && !stall)
+            gstore(q.hop + HOP_C + (q.lane >> 4) * 512 + 16 * q.member + (q.lane & 15), ep0 + 4 * l + 3,
+                   __float_as_uint(((const float*)(smem + L_STAGE))[q.lane]));
+        }
+      }
+      // ================= P3: FFN1 + ReLU
+      MG_BAR();                                                            // XS copy 0 holds LN1(y1) of quad 0
+      if (*st_abort(q)) return;
+      relaunder(q);
+      wload(wD, pm_src(l, WI_P2 + WI_P3));
+      for (int qd = 0; qd < nq; ++qd) {
+        if (qd > 0) {
+          MG_BAR();                                                        // XS copy qd & 1 holds LN1(y1)
+          if (*st_abort(q)) return;
+        }
+        relaunder(q);
+        set_quad(q, qd);
+        const int R = q.R;
+        q.hop = hop_slot(q, s, l);
+        const f4 p_bias = *(const f4*)(lp + FP_B1 + 64 * q.member + 32 * (q.cw & 1) + 4 * (q.lane >> 4));
+        const f4 p_bias2 = *(const f4*)(lp + FP_B1 + 64 * q.member + 32 * (q.cw & 1) + 16 + 4 * (q.lane >> 4));
+        gemm_chunk<4>(q, wC, (const _Float16*)(smem + L_XS) + (qd & 1) * RMAX * XS_LD, XS_LD, q.cw, q.cw * 4);
+        compute_barrier(q, cgen);
+        if (*st_abort(q)) return;
+        if (q.cw < 2) {
+          const f4* red = (const f4*)(smem + L_RED);
+          const int r = q.lane & 15;
+          unsigned* stage = (unsigned*)(smem + L_STAGE) + q.cw * 256;
+          if (r < R) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+              const int tile = 2 * q.cw + tt;
+              const f4 v0 = red[red_idx(0 * 4 + tile, q.lane)], v1 = red[red_idx(1 * 4 + tile, q.lane)],
+                       v2 = red[red_idx(2 * 4 + tile, q.lane)], v3 = red[red_idx(3 * 4 + tile, q.lane)];
+              f4 v = v0;
+              v += v1; v += v2; v += v3;
+              v += tt == 0 ? p_bias : p_bias2;
+              const int w0 = r * 16 + tt * 8 + 2 * (q.lane >> 4);
+              stage[w0] = pack_h2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+              stage[w0 + 1] = pack_h2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+            }
+          }
+          if (q.lane < R * 16)
+            gstore(q.hop + HOP_D + (q.lane >> 4) * 1024 + 32 * q.member + 16 * q.cw + (q.lane & 15), ep0 + 4 * l + 4, stage[q.lane]);
+        }
+      }
+      // ================= P4: FFN2
+      MG_BAR();                                                            // HS copy 0 holds quad 0's FFN hidden
+      if (*st_abort(q)) return;
+      relaunder(q);
+      if (l + 1 < a.L) wload(wA0, p1_src(l + 1));                          // P1 has finished with both halves for every quad
+      else wload(wA0, a.lpack + (((size_t)q.member * 4 + q.cw) * WI_LG * 512) / 8 + q.lane);
+      wload(wA1, p1_src(l + 1 < a.L ? l + 1 : 0) + (size_t)(WI_P1 / 2) * 64);
+      for (int qd = 0; qd < nq; ++qd) {
+        if (qd > 0) {
+          MG_BAR();                                                        // HS copy qd & 1 holds the FFN hidden
+          if (*st_abort(q)) return;
+        }
+        relaunder(q);
+        set_quad(q, qd);
+        const int R = q.R;
+        q.hop = hop_slot(q, s, l);
+        const f4 p_bias = *(const f4*)(lp + FP_B2 + 16 * q.member + 4 * (q.lane >> 4));
+        {
+          const int rowl = q.lane & 15, kg = q.lane >> 4;
+          f4* red = (f4*)(smem + L_RED);
+          f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int kc = 4 * q.cw + cc;
+            const _Float16* bp = (const _Float16*)(smem + L_HS) + ((qd & 1) * RMAX + (rowl & (RMAX - 1))) * HS_LD + kc * 128 + 8 * kg;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wD[cc * 4 + ks], *(const h8*)(bp + 32 * ks), acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (rowl < RMAX) red[red_idx(q.cw, q.lane)] = acc;
+        }
+        compute_barrier(q, cgen);
+        if (*st_abort(q)) return;
+        if (q.cw == 0) {
+          const f4* red = (const f4*)(smem + L_RED);
+          const int r = q.lane & 15;
+          if (r < R) {
+            const f4 v0 = red[red_idx(0, q.lane)], v1 = red[red_idx(1, q.lane)], v2 = red[red_idx(2, q.lane)], v3 = red[red_idx(3, q.lane)];
+            f4 v = v0;
+            v += v1; v += v2; v += v3;
+            v += p_bias;
+            v += *rs_at(smem, 1, qd, q.lane);
+            *(f4*)((float*)(smem + L_STAGE) + r * 16 + 4 * (q.lane >> 4)) = v;
+          }
+          const unsigned ep = l + 1 < a.L ? ep0 + 4 * (l + 1) + 1 : ep0 + 4 * a.L + 1;
+          if (q.lane < R * 16)
+            gstore(hop_slot(q, s, l + 1) + HOP_A + (q.lane >> 4) * 512 + 16 * q.member + (q.lane & 15), ep,
+                   __float_as_uint(((const float*)(smem + L_STAGE))[q.lane]));
+        }
+      }
+    }
+    // ================= tail: logits
+    const unsigned epE = ep0 + 4 * a.L + 2;
+    for (int qd = 0; qd < nq; ++qd) {
+      relaunder(q);
+      set_quad(q, qd);
+      const int R = q.R;
+      q.hop = hop_slot(q, s, a.L);
+      MG_BAR();                                                            // XS copy qd & 1 holds LN2(y) of the last layer
+      if (*st_abort(q)) return;
+      gemm_chunk<3>(q, wA0, (const _Float16*)(smem + L_XS) + (qd & 1) * RMAX * XS_LD, XS_LD, q.cw, q.cw * 3);
+      compute_barrier(q, cgen);
+      if (*st_abort(q)) return;
+      if (q.cw < 3) {
+        const f4* red = (const f4*)(smem + L_RED);
+        const int t = q.cw, r = q.lane & 15;
+        const int tile = t == 0 ? q.member : (t == 1 ? q.member + 32 : 64);
+        float* stage = (float*)(smem + L_STAGE) + q.cw * 256;
+        if (r < R) {
+          f4 v = red[red_idx(0 * 3 + t, q.lane)];
+          v += red[red_idx(1 * 3 + t, q.lane)]; v += red[red_idx(2 * 3 + t, q.lane)]; v += red[red_idx(3 * 3 + t, q.lane)];
+          *(f4*)(stage + r * 16 + 4 * (q.lane >> 4)) = v;
+        }
+        if (q.lane < R * 16 && (t < 2 || q.member == 0) && 16 * tile + (q.lane & 15) < V)
+          gstore(q.hop + HOP_E + (q.lane >> 4) * VPAD + 16 * tile + (q.lane & 15), epE, __float_as_uint(stage[q.lane]));
+      }
+    }
+    MG_BAR();                                                              // end of the step's GEMMs
+    if (*st_abort(q)) return;
+    wload(wA0, p1_src(0));                                                 // the next step's first slice follows the logits slice's last reader
+  }
+}
+
+// MODE 0: one quad per group (B <= 32); 1: several quads, one after the other in every phase (kept for A/B: GSV_MEGA_QUADS=seq);
+// 2: several quads, pipelined (default for 32 < B <= 128)
+template <int MODE>
 __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Ctx c;
@@ -1281,8 +1754,13 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   }
   __syncthreads();
   if (group_done(c)) return;
-  if (c.comm) comm_role<MULTI>(a, c, sp);
-  else compute_role<MULTI>(a, c);
+  if constexpr (MODE == 2) {
+    if (c.comm) comm_role_pipe(a, c, sp);
+    else compute_role_pipe(a, c);
+  } else {
+    if (c.comm) comm_role<MODE == 1>(a, c, sp);
+    else compute_role<MODE == 1>(a, c);
+  }
 }
 
 // census: are 256 workgroups of the engine's footprint co-resident?  Every workgroup arrives on a counter and waits
@@ -1361,12 +1839,16 @@ int mega_census(hipStream_t s, unsigned* d_scratch, unsigned* h_pinned) {
 int launch_t2s_mega(const MegaArgs& a, hipStream_t s) {
   // every launch: the attribute belongs to the (function, device) pair, and TTS.set_device may have moved the handle's owner
   // to another GPU of the process since the last launch (mega_census does the same)
-  if (a.B > RMAX * MG_GROUPS) {          // more than one quad per group
-    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
-    hipLaunchKernelGGL(t2s_mega_kernel<true>, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
+  static const bool seq_quads = getenv("GSV_MEGA_QUADS") && !strcmp(getenv("GSV_MEGA_QUADS"), "seq");
+  if (a.B > RMAX * MG_GROUPS && seq_quads) {          // more than one quad per group, one after the other (A/B)
+    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
+    hipLaunchKernelGGL(t2s_mega_kernel<1>, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
+  } else if (a.B > RMAX * MG_GROUPS) {                // pipelined quads
+    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
+    hipLaunchKernelGGL(t2s_mega_kernel<2>, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
   } else {
-    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
-    hipLaunchKernelGGL(t2s_mega_kernel<false>, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
+    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
+    hipLaunchKernelGGL(t2s_mega_kernel<0>, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
   }
   GSV_HIP(hipGetLastError());
   return GSV_OK;
