@@ -110,3 +110,50 @@ def test_config4_long_form_streams_in_reading_order(pipeline):
     assert whole.size == body.size
     print(f"[configs4] 140 sentences streamed on one GPU: {dt * 1e3:.0f} ms total = {140 * TOK * 0.04 / dt:.0f} audio-s/s, first "
           f"fragment after {(first_at - t0) * 1e3:.0f} ms")
+
+
+def test_two_pipelines_on_separate_streams_keep_the_engine_correct(pipeline):
+    """The persistent AR engine assumes its 256 workgroups co-resident (census once per handle).  Here a
+    second TTS instance keeps its SoVITS decode and its own AR engine busy on other streams from another host thread while the
+    first one runs full batches on the default separate engine streams: every result must equal the instance's solo result
+    (the bounded hand-offs either complete or are re-run on the launch path -- never wrong audio), and the fallbacks taken
+    are reported."""
+    import threading
+    from gsv.TTS_infer_pack.TTS import TTS
+    tts, synth, calls = pipeline
+    segs = _segments(32)
+    solo, _ = synth(segs)
+    t2s_cfg = {k: dict(v) for k, v in S.T2S_V2_CONFIG.items()}
+    t2s_cfg["data"]["max_sec"] = TOK / 50.0
+    other = TTS({"device": DEV, "is_half": True, "version": "v2", "max_batch": B, "max_seq": 80 + 100 + TOK + 16})
+    other.init_t2s_weights(state={"weight": S.make_t2s_state_dict(S.T2S_V2_CONFIG, seed=0, suppress_eos=True), "config": t2s_cfg})
+    other.init_vits_weights(state={"weight": S.make_vits_state_dict(S.VITS_V2_CONFIG, seed=0), "config": dict(S.VITS_V2_CONFIG)})
+    utt = S.make_utterances(1)
+    other.set_prompt_cache(utt["prompt_semantic"], [S.make_refer_spec().to(DEV)], phones=utt["prompt_phones"],
+                           bert_features=torch.zeros(1024, len(utt["prompt_phones"])), norm_text="x" * 40)
+    params = dict(batch_size=B, top_k=1, top_p=1.0, temperature=1.0, repetition_penalty=1.35, seed=0, split_bucket=True,
+                  parallel_infer=True, fragment_interval=0.3)
+    stop = threading.Event()
+    other_out, errs = [], []
+
+    def background():
+        try:
+            while not stop.is_set():
+                for _sr, a in other.run(dict(params, segments=segs)):
+                    other_out.append(a)
+        except Exception as e:                                   # noqa: BLE001
+            errs.append(e)
+
+    th = threading.Thread(target=background)
+    th.start()
+    try:
+        for _ in range(6):
+            got, lens = synth(segs)
+            assert np.array_equal(got, solo), "a batch computed beside another pipeline's kernels differs from the solo result"
+    finally:
+        stop.set()
+        th.join(timeout=120)
+    assert not errs, errs
+    assert len(other_out) >= 1 and all(np.array_equal(a, solo) for a in other_out), "the background pipeline's audio is wrong"
+    fb = tts.t2s_model.engine_stats()[1] + other.t2s_model.engine_stats()[1]
+    print(f"[engine] two pipelines side by side: {6 + len(other_out)} batches, all equal to the solo result; hand-off fallbacks taken: {fb}")

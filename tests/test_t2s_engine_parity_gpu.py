@@ -288,3 +288,21 @@ def test_lost_handoff_ends_the_launch_and_the_batch_is_rerun_on_the_launch_path(
     y2, _ = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
     assert [y.tolist() for y in y2] == [y.tolist() for y in y0]
     assert eng.engine_stats()[1] == 2
+
+
+def test_lost_handoff_in_a_multi_quad_launch():
+    """the same for a launch with several quads per group (B = 40: the pipelined-quad kernel)"""
+    cfg, sd = _v2()
+    eng = _engine(cfg, sd, max_batch=64, max_seq=320)
+    xs, berts, prompts = _batch(40)
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, early_stop_num=10, repetition_penalty=1.35)
+    eng.set_mega(False)
+    yb, ib = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    eng.set_mega(True)
+    eng.debug_stall(7)
+    ya, ia = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    avail, fb, err3 = eng.engine_stats()
+    assert eng.decode_info()[0] == 0 and fb == 1 and (err3[2] & 0xff) == 4
+    assert ia == ib and [y.tolist() for y in ya] == [y.tolist() for y in yb]
+    y1, _ = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    assert eng.decode_info()[0] == 1
