@@ -442,7 +442,16 @@ __device__ __forceinline__ void gemm_chunk(const Ctx& c, const h8 (&w)[NT * 4], 
 template <int N>
 __device__ __forceinline__ void wload(h8 (&dst)[N], const h8* src) {
 #pragma unroll
+  // DEFAULT cache policy, not non-temporal: the 8 workgroups of an XCD that stream the same slice (one per row group) then
+  // share one fill of the XCD's L2; with `nt` loads the line was kept only when the eight requests happened to arrive close
+  // together -- that was the two run-to-run modes (~319 / ~343 us per step), and the memory-side traffic swinging between
+  // 1.28 and 1.79 x the algorithmic bytes.  Measured, 5 alternating pairs: 334-345 -> 301-303 us per step at B = 32,
+  // 838 -> 790 at B = 128 (-DGSV_MEGA_W_NT restores the non-temporal loads).
+#ifdef GSV_MEGA_W_NT
   for (int i = 0; i < N; ++i) dst[i] = __builtin_nontemporal_load(src + (size_t)i * 64);
+#else
+  for (int i = 0; i < N; ++i) dst[i] = src[(size_t)i * 64];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
