@@ -394,16 +394,16 @@ def main():
         # --- stage breakdown of the last step (reference prints the same four numbers, TTS.py:1320)
         t_text, t_batch, t_ar, t_dec = tts.last_timing
         vt_total, vt_gen = tts.vits_model.last_timing()
-        # --- roofline of the kernel with the largest share of GPU time (profiles/r02_bench_kernel_stats.csv): the persistent
+        # --- roofline of the kernel with the largest share of GPU time (profiles/r03_bench_kernel_stats.csv): the persistent
         # AR decode engine.  One launch covers every decode step after step 0 of the batch; its algorithmic bytes are the
         # steps' weight + K/V bytes, its duration comes from HIP events on the engine stream.
         mode, dec_ms, dec_steps = tts.t2s_model.decode_info()
         attn_ms, attn_bytes, step_bytes, layers_ms = tts.t2s_model.time_attention(iters=10)
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r02_mega_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r03_mega_traffic.json")
         if os.path.exists(tj) and B == 32 and TOK == 100 and not args.fp32 and mode == 1:
             traffic = json.load(open(tj)).get("traffic_bytes_per_launch")
-            traffic_src = "profiles/r02_mega_traffic.json (PMC passes of this command, replayed here)"
+            traffic_src = "profiles/r03_mega_traffic.json (PMC passes of this command, replayed here)"
         if mode == 1 and dec_steps > 0:
             # K/V grows by one position per step: bytes at the end-of-run cache length minus the shortfall of earlier steps
             kv_pos_bytes = attn_bytes / max(1, (80 + 100 + TOK)) if attn_bytes else 0      # one cached position, all rows, one layer
