@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import re
 import threading
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Callable, Dict, Iterable, Iterator, List, Optional, Tuple
 
 import torch
 
@@ -35,21 +35,29 @@ def get_first(text: str) -> str:
     return re.split(pattern, text)[0].strip()
 
 
+def _merged(pieces: Iterable[str], threshold: int) -> Iterator[str]:
+    """yield runs of consecutive pieces, each run closed as soon as it holds `threshold` characters; what is left over at
+    the end is yielded too (the caller decides where it goes)"""
+    run = ""
+    for piece in pieces:
+        run += piece
+        if len(run) >= threshold:
+            yield run
+            run = ""
+    if run:
+        yield run
+
+
 def merge_short_text_in_array(texts: List[str], threshold: int) -> List[str]:
+    """reference TextPreprocessor.py:32-48: short pieces are glued to their successors until a run reaches `threshold`
+    characters; a short tail joins the last full run (or stands alone when there is none)"""
     if len(texts) < 2:
         return texts
-    result, text = [], ""
-    for ele in texts:
-        text += ele
-        if len(text) >= threshold:
-            result.append(text)
-            text = ""
-    if len(text) > 0:
-        if len(result) == 0:
-            result.append(text)
-        else:
-            result[-1] += text
-    return result
+    runs = list(_merged(texts, threshold))
+    if len(runs) > 1 and len(runs[-1]) < threshold:
+        tail = runs.pop()
+        runs[-1] += tail
+    return runs
 
 
 _KANA = re.compile(r"[ぁ-ゖ゙゚ァ-ヺー]")
@@ -107,81 +115,75 @@ class TextPreprocessor:
             result.append({"phones": phones, "bert_features": bert_features, "norm_text": norm_text})
         return result
 
-    # ---- reference :79-117
+    # ---- reference :79-117, as a chain of small stages
     def pre_seg_text(self, text: str, lang: str, text_split_method: str) -> List[str]:
+        stop = "." if lang == "en" else "。"
         text = text.strip("\n")
-        if len(text) == 0:
+        if not text:
             return []
-        if text[0] not in splits and len(get_first(text)) < 4:
-            text = "。" + text if lang != "en" else "." + text
-        text = get_seg_method(text_split_method)(text)
-        while "\n\n" in text:
-            text = text.replace("\n\n", "\n")
-        _texts = merge_short_text_in_array(self.filter_text(text.split("\n")), 5)
-        texts: List[str] = []
-        for text in _texts:
-            if len(text.strip()) == 0:
-                continue
-            if not re.sub(r"\W+", "", text):
-                continue                                   # symbols only
-            if text[-1] not in splits:
-                text += "。" if lang != "en" else "."
-            if len(text) > 510:                            # BERT's input limit
-                texts.extend(split_big_text(text))
-            else:
-                texts.append(text)
-        return texts
+        if text[0] not in splits and len(get_first(text)) < 4:      # a very short first sentence gets a leading stop
+            text = stop + text
+        cut = re.sub(r"\n{2,}", "\n", get_seg_method(text_split_method)(text))
+        pieces = merge_short_text_in_array(self.filter_text(cut.split("\n")), 5)
+
+        def speakable(items):
+            for t in items:
+                if t.strip() and re.sub(r"\W+", "", t):              # not blank, not symbols only
+                    yield t
+
+        def terminated(items):
+            for t in items:
+                yield t if t[-1] in splits else t + stop
+
+        def bounded(items):
+            for t in items:
+                if len(t) > 510:                                     # BERT's input limit
+                    yield from split_big_text(t)
+                else:
+                    yield t
+
+        return list(bounded(terminated(speakable(pieces))))
 
     def segment_and_extract_feature_for_text(self, text: str, language: str, version: str = "v1"):
         return self.get_phones_and_bert(text, language, version)
 
     # ---- reference :122-190
+    # How a request language is routed to (language, text) runs, as data: the hint given to the segmenter for Han characters,
+    # and what a detected "zh" run is relabelled to.
+    _MONO = {"all_zh": ("zh", None), "all_ja": ("ja", None), "all_ko": ("ko", None), "all_yue": ("zh", "yue"),
+             "auto": (None, None), "auto_yue": (None, "yue")}
+
+    def _runs(self, text: str, language: str) -> List[Tuple[str, str]]:
+        if language == "en":
+            return [("en", text)]
+        if language in self._MONO:
+            hint, zh_as = self._MONO[language]
+            return [(zh_as if zh_as and seg["lang"] == "zh" else seg["lang"], seg["text"]) for seg in self.lang_segmenter(text, hint)]
+        # a plain language ("zh", "ja", ...): English runs stay English, every other run is the caller's language -- Han characters
+        # of zh / ja / ko cannot be told apart -- and neighbours of the same kind are glued together
+        runs: List[Tuple[str, str]] = []
+        for seg in self.lang_segmenter(text, None):
+            kind = "en" if seg["lang"] == "en" else language
+            if runs and (runs[-1][0] == "en") == (kind == "en"):
+                runs[-1] = (runs[-1][0], runs[-1][1] + seg["text"])
+            else:
+                runs.append((kind, seg["text"]))
+        return runs
+
     def get_phones_and_bert(self, text: str, language: str, version: str, final: bool = False):
         with self.bert_lock:
             text = re.sub(r" {2,}", " ", text)
-            textlist: List[str] = []
-            langlist: List[str] = []
-            seg = self.lang_segmenter
-            if language in ("all_zh", "all_yue", "all_ja", "all_ko"):
-                base = language[4:]
-                for tmp in seg(text, "zh" if base == "yue" else base):
-                    lang = tmp["lang"]
-                    if base == "yue" and lang == "zh":
-                        lang = "yue"
-                    langlist.append(lang)
-                    textlist.append(tmp["text"])
-            elif language == "en":
-                langlist.append("en")
-                textlist.append(text)
-            elif language in ("auto", "auto_yue"):
-                for tmp in seg(text, None):
-                    lang = tmp["lang"]
-                    if language == "auto_yue" and lang == "zh":
-                        lang = "yue"
-                    langlist.append(lang)
-                    textlist.append(tmp["text"])
-            else:
-                for tmp in seg(text, None):
-                    if langlist:
-                        if (tmp["lang"] == "en" and langlist[-1] == "en") or (tmp["lang"] != "en" and langlist[-1] != "en"):
-                            textlist[-1] += tmp["text"]
-                            continue
-                    # Han characters of zh / ja / ko cannot be told apart: the caller's language decides
-                    langlist.append("en" if tmp["lang"] == "en" else language)
-                    textlist.append(tmp["text"])
-            phones_list, bert_list, norm_text_list = [], [], []
-            for i in range(len(textlist)):
-                lang = langlist[i]
-                phones, word2ph, norm_text = self.clean_text_inf(textlist[i], lang, version)
-                bert_list.append(self.get_bert_inf(phones, word2ph, norm_text, lang))
-                phones_list.append(phones)
-                norm_text_list.append(norm_text)
-            bert = torch.cat(bert_list, dim=1)
-            phones = sum(phones_list, [])
-            norm_text = "".join(norm_text_list)
-            if not final and len(phones) < 6:
+            phones: List[int] = []
+            berts: List[torch.Tensor] = []
+            norm_text = ""
+            for lang, piece in self._runs(text, language):
+                ph, word2ph, norm = self.clean_text_inf(piece, lang, version)
+                berts.append(self.get_bert_inf(ph, word2ph, norm, lang))
+                phones += ph
+                norm_text += norm
+            if not final and len(phones) < 6:                       # too short to synthesise: once more behind a leading stop
                 return self.get_phones_and_bert("." + text, language, version, final=True)
-            return phones, bert, norm_text
+            return phones, torch.cat(berts, dim=1), norm_text
 
     # ---- reference :191-204
     def get_bert_feature(self, text: str, word2ph: list) -> torch.Tensor:
@@ -205,11 +207,15 @@ class TextPreprocessor:
         return torch.zeros((1024, len(phones)), dtype=torch.float32, device=self.device)
 
     # ---- reference :222-239
+    _EMPTY = (None, " ", "")
+
     def filter_text(self, texts):
-        if all(text in [None, " ", "\n", ""] for text in texts):
+        kept = [t for t in texts if t not in self._EMPTY]
+        if not any(t != "\n" for t in kept):
             raise ValueError("请输入有效文本")
-        return [t for t in texts if t not in [None, " ", ""]]
+        return kept
+
+    _REPEATED_PUNCT = re.compile("([{0}])[{0}]+".format("".join(re.escape(c) for c in sorted(punctuation))))
 
     def replace_consecutive_punctuation(self, text: str) -> str:
-        p = "".join(re.escape(c) for c in punctuation)
-        return re.sub(f"([{p}])([{p}])+", r"\1", text)
+        return self._REPEATED_PUNCT.sub(r"\1", text)

@@ -17,7 +17,8 @@ from typing import Dict, List, Optional, Tuple
 
 from . import table
 
-special = [("￥", "zh", "SP2"), ("^", "zh", "SP3")]          # cleaner.py:13-18
+# silence marks (reference cleaner.py:13-18): (mark, language it applies to, symbol it becomes)
+special = [("￥", "zh", "SP2"), ("^", "zh", "SP3")]
 
 _LANGS = {"v1": ("zh", "ja", "en"), "v2": ("zh", "ja", "en", "ko", "yue")}      # cleaner.py:26-30
 _registry: Dict[str, object] = {}
@@ -40,44 +41,49 @@ def _backend(language: str):
     return _registry[language]
 
 
-def clean_text(text: str, language: str, version: Optional[str] = None) -> Tuple[List[str], Optional[List[int]], str]:
-    if version is None:
-        version = os.environ.get("version", "v2")
-    key = "v1" if version == "v1" else "v2"
-    symbols = table(key).to_id
-    if language not in _LANGS[key]:            # cleaner.py:32-34
-        language, text = "en", " "
-    for special_s, special_l, target_symbol in special:
-        if special_s in text and language == special_l:
-            return clean_special(text, language, special_s, target_symbol, version)
+def _table_key(version: Optional[str]) -> str:
+    return "v1" if (version or os.environ.get("version", "v2")) == "v1" else "v2"
+
+
+# What a language's G2P returns and how its phones are finished, as data (reference cleaner.py:36-52 spells it as an if-chain):
+#   aligned  -- g2p returns (phones, word2ph) and both must line up with the normalised text (zh, yue)
+#   min_len  -- fewer phones than this get a leading "," (en: 4)
+_SHAPE = {"zh": {"aligned": True}, "yue": {"aligned": True}, "en": {"min_len": 4}}
+
+
+def _run_g2p(language: str, text: str):
+    """-> (phones, word2ph or None, normalised text) of one language's back-end"""
     mod = _backend(language)
-    norm_text = mod.text_normalize(text) if hasattr(mod, "text_normalize") else text
-    if language in ("zh", "yue"):
-        phones, word2ph = mod.g2p(norm_text)
-        assert len(phones) == sum(word2ph)
-        assert len(norm_text) == len(word2ph)
-    elif language == "en":
-        phones = list(mod.g2p(norm_text))
-        if len(phones) < 4:
-            phones = [","] + phones
-        word2ph = None
-    else:
-        phones = list(mod.g2p(norm_text))
-        word2ph = None
-    phones = ["UNK" if ph not in symbols else ph for ph in phones]
-    return phones, word2ph, norm_text
+    norm = mod.text_normalize(text) if hasattr(mod, "text_normalize") else text
+    shape = _SHAPE.get(language, {})
+    out = mod.g2p(norm)
+    if shape.get("aligned"):
+        phones, word2ph = out
+        assert len(phones) == sum(word2ph) and len(norm) == len(word2ph)
+        return list(phones), word2ph, norm
+    phones = list(out)
+    if len(phones) < shape.get("min_len", 0):
+        phones.insert(0, ",")
+    return phones, None, norm
+
+
+def clean_text(text: str, language: str, version: Optional[str] = None) -> Tuple[List[str], Optional[List[int]], str]:
+    key = _table_key(version)
+    known = table(key).to_id
+    if language not in _LANGS[key]:            # an unknown language is synthesised as one English blank (cleaner.py:32-34)
+        language, text = "en", " "
+    mark = next(((m, sym) for m, lang, sym in special if lang == language and m in text), None)
+    if mark is not None:
+        return clean_special(text, language, mark[0], mark[1], version)
+    phones, word2ph, norm = _run_g2p(language, text)
+    return [ph if ph in known else "UNK" for ph in phones], word2ph, norm
 
 
 def clean_special(text: str, language: str, special_s: str, target_symbol: str, version: Optional[str] = None):
     """cleaner.py:58-83: the silence marks become "," for G2P and are mapped back to SP2 / SP3 afterwards."""
-    key = "v1" if (version or os.environ.get("version", "v2")) == "v1" else "v2"
-    symbols = table(key).to_id
-    text = text.replace(special_s, ",")
+    known = table(_table_key(version)).to_id
     mod = _backend(language)
-    norm_text = mod.text_normalize(text)
-    phones = mod.g2p(norm_text)
-    new_ph = []
-    for ph in phones[0]:
-        assert ph in symbols
-        new_ph.append(target_symbol if ph == "," else ph)
-    return new_ph, phones[1], norm_text
+    norm = mod.text_normalize(text.replace(special_s, ","))
+    phones, word2ph = mod.g2p(norm)
+    assert all(ph in known for ph in phones)
+    return [target_symbol if ph == "," else ph for ph in phones], word2ph, norm
