@@ -1154,13 +1154,28 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
           // one accumulator over the wave's four 128-wide chunks (the MFMA forwards a dependent accumulator without a stall):
           // ONE partial per wave like the other phases, instead of 16 per workgroup through LDS
           f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+          // the operand reads of chunk cc + 1 are in flight under the MFMAs of chunk cc (two register sets of 4 fragments; same
+          // MFMA order, bit-identical): 295.8 -> 292.6 us per step over 4 pairs (3 of 4), profiles/r03_ab_ffn2_operand_prefetch.txt
+          const _Float16* bp0 = (const _Float16*)(smem + L_HS) + (rowl & (RMAX - 1)) * HS_LD + (4 * q.cw) * 128 + 8 * kg;
+          h8 bA[4], bB[4];
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const int kc = 4 * q.cw + cc;
-            const _Float16* bp = (const _Float16*)(smem + L_HS) + (rowl & (RMAX - 1)) * HS_LD + kc * 128 + 8 * kg;
+          for (int ks = 0; ks < 4; ++ks) bA[ks] = *(const h8*)(bp0 + 32 * ks);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wD[cc * 4 + ks], *(const h8*)(bp + 32 * ks), acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);       // keep the 16 operand reads from being hoisted in front of the first MFMA
+          for (int cc = 0; cc < 4; cc += 2) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bB[ks] = *(const h8*)(bp0 + (cc + 1) * 128 + 32 * ks);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wD[cc * 4 + ks], bA[ks], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (cc + 2 < 4) {
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) bA[ks] = *(const h8*)(bp0 + (cc + 2) * 128 + 32 * ks);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wD[(cc + 1) * 4 + ks], bB[ks], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
           if (rowl < RMAX) red[red_idx(q.cw, q.lane)] = acc;
         }
@@ -1621,12 +1636,25 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
           const int rowl = q.lane & 15, kg = q.lane >> 4;
           f4* red = (f4*)(smem + L_RED);
           f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+          const _Float16* bp0 = (const _Float16*)(smem + L_HS) + ((qd & 1) * RMAX + (rowl & (RMAX - 1))) * HS_LD + (4 * q.cw) * 128 + 8 * kg;
+          h8 bA[4], bB[4];                                   // chunk cc + 1's operands in flight under chunk cc's MFMAs (see compute_role)
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const int kc = 4 * q.cw + cc;
-            const _Float16* bp = (const _Float16*)(smem + L_HS) + ((qd & 1) * RMAX + (rowl & (RMAX - 1))) * HS_LD + kc * 128 + 8 * kg;
+          for (int ks = 0; ks < 4; ++ks) bA[ks] = *(const h8*)(bp0 + 32 * ks);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wD[cc * 4 + ks], *(const h8*)(bp + 32 * ks), acc, 0, 0, 0);
+          for (int cc = 0; cc < 4; cc += 2) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bB[ks] = *(const h8*)(bp0 + (cc + 1) * 128 + 32 * ks);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wD[cc * 4 + ks], bA[ks], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (cc + 2 < 4) {
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) bA[ks] = *(const h8*)(bp0 + (cc + 2) * 128 + 32 * ks);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wD[(cc + 1) * 4 + ks], bB[ks], acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
           if (rowl < RMAX) red[red_idx(q.cw, q.lane)] = acc;
