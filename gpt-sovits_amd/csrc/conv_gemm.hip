@@ -13,6 +13,8 @@
 // operands are still fetched as 16-byte contiguous chunks.
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "common.h"
 
 namespace gsv {
@@ -225,6 +227,11 @@ int launch_conv_gemm(int dtype, const ConvArgs& a_in, hipStream_t s) {
     rc = launch_conv_lds(dtype, a, s);
     if (rc <= 0) return rc;
   }
+  static const bool trace = getenv("GSV_TRACE_CONV_GEMM") != nullptr;      // which shapes take the direct-from-global fallback
+  if (trace)
+    fprintf(stderr, "[conv_gemm fallback] T_in %d T_virt %d Cin %d Cout %d taps %d stride %d dil %d Z %d res %d res_f32 %d acc %d out_f32 %d gate %d ups %d\n",
+            a.T_in, a.T_virt, a.Cin, a.Cout, a.taps, a.stride, a.dil, a.Z, a.res != nullptr, a.res_f32, a.accumulate, a.out_f32,
+            a.gate != nullptr, a.ups_u);
   if (dtype == GSV_F16) return launch_t<_Float16>(a, s);
   if (dtype == GSV_F32) return launch_t<float>(a, s);
   set_error("conv_gemm: bad dtype %d", dtype);
