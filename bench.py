@@ -252,11 +252,13 @@ def extra_total_1024_b128(dev, TOK, params, prompt_args, make_segs):
 def extra_long_form(sh, make_segs, B, tok_count):
     """BASELINE configs[4] on ONE GPU: a 1400-word text = 140 sentences of 10 words, streamed in reading order (batches of B in
     submission order, `wire.streaming_generator` framing): throughput and the time to the first audible fragment."""
+    import gc
     from gsv import wire
     _utt, segs = make_segs(140)
     tok_count[0] = 0
     first = [None]
-    torch.cuda.synchronize()
+    gc.collect()                       # the 1024-utterance job before this left ~10^5 host objects: a generation-2 collection inside the
+    torch.cuda.synchronize()           # first batch would be charged to the time to the first fragment (seen: 57 vs 135 ms)
     t0 = time.perf_counter()
 
     def gen():
