@@ -306,3 +306,62 @@ def test_lost_handoff_in_a_multi_quad_launch():
     assert ia == ib and [y.tolist() for y in ya] == [y.tolist() for y in yb]
     y1, _ = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
     assert eng.decode_info()[0] == 1
+
+
+def test_multi_quad_sampling_replay_and_long_caches():
+    """the pipelined-quad kernel (32 < B <= 128) under the conditions the single-quad tests above cover: (1) sampling inside
+    the engine at B = 77 (top-k 15, temperature 0.9, counter RNG keyed by the BATCH row, repetition bookkeeping per sampler
+    member), replayed step by step with the sampling kernel alone on the engine's own logits; (2) rows whose cache exceeds the
+    320-position LDS image and rows that cross it mid-decode at B = 40 (quads of a group mix short and long rows), teacher-
+    forced per-step logits vs the launch path."""
+    from gsv import _lib
+    from gsv import synthetic as S
+    cfg, sd = _v2()
+    eng = _engine(cfg, sd, max_batch=128, max_seq=832)
+    # ---- (1)
+    B, N, V = 77, 24, 1025
+    xs, berts, prompts = _batch(B)
+    P = prompts.shape[1]
+    kw = dict(top_k=15, top_p=1.0, temperature=0.9, early_stop_num=N, repetition_penalty=1.35, seed=4242)
+    eng.set_mega(False)
+    yb, ib = eng.infer_panel_batch_infer(xs, None, prompts, berts, **kw)
+    eng.set_mega(True)
+    assert ib == [N] * B
+    tok = _gen(yb, P, N)
+    ya, ia, La, Da, mode = _forced(eng, xs, berts, prompts, tok, kw, True)
+    assert mode == 1
+    l = _lib.lib()
+    sp = _lib.SamplingParams(15, 1.0, 0.9, 1.35, -1, 1, N + 1, 4242)
+    hist = torch.cat([prompts.to(torch.int32), tok.to(DEV)], 1).contiguous()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bad = 0
+    for st in range(N + 1):
+        lg = torch.from_numpy(La[st]).to(DEV).contiguous()
+        prev = hist[:, :P + st].contiguous()
+        smp = torch.zeros(B, dtype=torch.int32, device=DEV)
+        amx = torch.zeros(B, dtype=torch.int32, device=DEV)
+        _lib.check(l.gsv_op_sample(lg.data_ptr(), B, V, V - 1 if st < 1 else V, prev.data_ptr(), P + st, C.byref(sp), None, st,
+                                   smp.data_ptr(), amx.data_ptr(), s))
+        torch.cuda.synchronize()
+        bad += int((smp.cpu().numpy() != Da[st, :, 0]).sum()) + int((amx.cpu().numpy() != Da[st, :, 1]).sum())
+    assert bad == 0, f"{bad} drawn / argmax tokens of the multi-quad engine differ from the sampling kernel's replay"
+    # ---- (2)
+    B2, N2 = 40, 26
+    g = torch.Generator().manual_seed(11)
+    lens = [150 + (37 * i) % 80 for i in range(B2)]            # caches 251 .. 330 at step 1: many rows cross 320 within 26 steps
+    lens[3], lens[17], lens[36] = 400, 600, 221                 # and a few far beyond it / exactly at it
+    xs2 = [torch.randint(0, 732, (n,), generator=g).to(DEV) for n in lens]
+    pr2 = S.make_utterances(1)["prompt_semantic"].unsqueeze(0).expand(B2, -1).contiguous().to(DEV)
+    kw2 = dict(top_k=1, top_p=1.0, temperature=1.0, early_stop_num=N2, repetition_penalty=1.35)
+    eng.set_mega(False)
+    yl, il = eng.infer_panel_batch_infer(xs2, None, pr2, [None] * B2, dump_logits=True, **kw2)
+    Lb = eng.last_logits_dump.cpu().numpy()
+    eng.set_mega(True)
+    assert il == [N2] * B2
+    tok2 = _gen(yl, 100, N2)
+    ya2, ia2, La2, Da2, mode2 = _forced(eng, xs2, [None] * B2, pr2, tok2, kw2, True)
+    assert mode2 == 1 and np.isfinite(La2).all()
+    err = np.abs(La2 - Lb).max(2)
+    print(f"[parity] multi-quad engine, caches 251 .. 700 crossing the LDS image: teacher-forced logits vs launch path max {err.max():.3e} "
+          f"(row of the maximum: cache {lens[int(err.max(0).argmax())] + 100})")
+    assert err.max() <= 4e-2
