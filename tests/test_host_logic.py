@@ -77,6 +77,18 @@ def test_to_batch_and_recovery_order_match_the_reference_methods():
         assert tts.recovery_order([[str(i) for i in b] for b in index], index) == [str(i) for i in range(len(lens))]
 
 
+def test_make_batches_first_batch_and_reading_order():
+    lens = [5, 1, 4, 2, 3, 9, 8]
+    assert sharding.make_batches(lens, 3) == [[1, 3, 4], [2, 0, 6], [5]]
+    assert sharding.make_batches(lens, 3, bucket=False) == [[0, 1, 2], [3, 4, 5], [6]]
+    assert sharding.make_batches(lens, 3, bucket=False, first_batch=1) == [[0], [1, 2, 3], [4, 5, 6]]
+    assert sharding.make_batches(lens, 3, bucket=False, first_batch=3) == [[0, 1, 2], [3, 4, 5], [6]]      # not smaller: ignored
+    got = list(sharding.ShardedSynthesizer(_stub_synth, torch.device("cpu")).run_stream(
+        [{"phones": [i + 1] * 2, "bert_features": None, "norm_text": "x" * n} for i, n in enumerate(lens)], batch_size=3,
+        bucket=False, first_batch=2))
+    assert [idx for idx, _ in got] == [[0, 1], [2, 3, 4], [5, 6]]
+
+
 def test_deal_contiguous_batches_and_wire_format_roundtrip():
     lens = [5, 1, 9, 3, 7, 2, 8]
     shares = sharding.deal_contiguous(lens, 3)
