@@ -242,7 +242,10 @@ def extra_total_1024_b128(dev, TOK, params, prompt_args, make_segs):
     out = sh.run(segs, batch_size=B)
     dt = time.perf_counter() - t0
     mode, ms, steps = ar_ms[-1]
+    _attn_ms, _attn_bytes, step_bytes, _layers_ms = tts.t2s_model.time_attention(iters=2)     # algorithmic bytes of one step at the final cache state
+    frac = round(step_bytes / (ms / steps * 1e-3) / 8e12, 4) if mode == 1 and steps else None
     return {"workload": "BASELINE configs[2] on one GPU: 1024 utterances, 8 batches of 128 (one persistent AR launch per batch), fp16",
+            "ar_step_algorithmic_bytes": int(step_bytes), "ar_step_hbm_frac": frac,
             "value": round(toks[0] * 0.04 / dt, 1), "unit": "audio_s/s", "ms": round(1e3 * dt, 1), "utterances": 1024,
             "samples": int(out.size), "ar_decode_mode": "persistent engine" if mode == 1 else "launch per phase",
             "ar_step_ms": round(ms / steps, 4) if mode == 1 and steps else None,
