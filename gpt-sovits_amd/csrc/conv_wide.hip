@@ -29,13 +29,15 @@ __device__ __forceinline__ void mma32w(f16v& acc, const h8& a, const h8& b) { ac
 __device__ __forceinline__ h8 lrelu8w(h8 v, float s) { h8 t = v * (_Float16)s; return __builtin_elementwise_max(v, t); }
 __device__ __forceinline__ h8 relu8w(h8 v) { return __builtin_elementwise_max(v, (h8){0, 0, 0, 0, 0, 0, 0, 0}); }
 
-template <bool RES, bool ACCU>
-__global__ __launch_bounds__(256) void conv_wide_f16_kernel(ConvArgs a, int rows_win, int ntiles) {
-  constexpr int G = 8, KC = 16, CC = 128, CT = 128, TM = 2, TN = 4, WN = 2, NT = 256;
+// NW = waves per workgroup: 4 (each wave 64 channels x 128 steps) or 8 (64 x 64: two waves per SIMD, so that one wave's LDS
+// operand reads and waits overlap the other's MFMAs -- with one wave per SIMD every stall of the tap loop is exposed)
+template <bool RES, bool ACCU, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_wide_f16_kernel(ConvArgs a, int rows_win, int ntiles) {
+  constexpr int G = 8, KC = 16, CC = 128, CT = 128, TM = 2, TN = NW == 8 ? 2 : 4, WN = NW == 8 ? 4 : 2, NT = NW * 64;
   constexpr int LDX = CC + G, VPR = CC / G;             // 136, 16
   constexpr int WLOADS = CT * VPR / NT;                 // 8 vectors per thread per tap slab
   constexpr int XB = (306 * VPR + NT - 1) / NT;         // 20 vectors per thread per window
-  constexpr int LDO = CT + 4, PR = TN * 32, IPR = CT / 4, NI = PR * IPR / NT;   // 128 rows per epilogue pass, 16 items per thread
+  constexpr int LDO = CT + 4, PR = TN * 32, IPR = CT / 4, NI = PR * IPR / NT;   // 128 (64) rows per epilogue pass, 16 (4) items per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = (T*)smem;                                     // [rows_win <= 306][LDX]; the fp32 epilogue tile [PR][LDO] aliases it
   T* ws = xs + (size_t)306 * LDX;                       // [2][CT][LDX]
@@ -236,18 +238,23 @@ int launch_conv_wide(int dtype, const ConvArgs& a, hipStream_t s) {
   if (getenv("GSV_WIDE_PROF") && !d_prof) { (void)hipMalloc((void**)&d_prof, 64 * 8); (void)hipMemset(d_prof, 0, 64 * 8); }
   b.prof = d_prof;
   const bool res = a.res != nullptr, acc = a.accumulate != 0;
-#define GSV_WIDE(R, A)                                                                                                     \
+  // 8 waves (round 3): 246 -> 222 us at 7 taps, 309 -> 291 us at 11 taps (tools/conv_probe.py), generator 10.87 -> 10.37 ms per bench
+  // step in 2 of 2 alternating pairs, 0 / 10 spilled VGPRs instead of 0 / 22-58; GSV_WIDE_WAVES=4 restores round 2's geometry
+  static const int nw = getenv("GSV_WIDE_WAVES") ? atoi(getenv("GSV_WIDE_WAVES")) : 8;
+#define GSV_WIDE_NW(R, A, W)                                                                                               \
   do {                                                                                                                     \
-    auto kern = conv_wide_f16_kernel<R, A>;                                                                                \
+    auto kern = conv_wide_f16_kernel<R, A, W>;                                                                             \
     static bool set = false;                                                                                               \
     if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b, rows_win, ntiles);                                          \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(W * 64), lds, s, b, rows_win, ntiles);                                       \
   } while (0)
+#define GSV_WIDE(R, A) do { if (nw == 8) GSV_WIDE_NW(R, A, 8); else GSV_WIDE_NW(R, A, 4); } while (0)
   if (res && acc) GSV_WIDE(true, true);
   else if (res) GSV_WIDE(true, false);
   else if (acc) GSV_WIDE(false, true);
   else GSV_WIDE(false, false);
 #undef GSV_WIDE
+#undef GSV_WIDE_NW
   GSV_HIP(hipGetLastError());
   if (d_prof && ++prof_calls == 3) {
     (void)hipStreamSynchronize(s);
