@@ -821,6 +821,14 @@ template <typename T> static int try_launch(const ConvArgs& a, hipStream_t s) {
       if (a.Cin >= CCBIG && fits<T, 128, CCBIG>(rows128)) return launch_inst<T, 2, 2, 2, 2, CCBIG, false>(a, rows128, lo, s);
       if (a.Cin >= CCBIG / 2 && fits<T, 128, CCBIG / 2>(rows128)) return launch_inst<T, 2, 2, 2, 2, CCBIG / 2, false>(a, rows128, lo, s);
     }
+    // 8 waves (64 channels x 64 steps per wave, two waves per SIMD: one wave's LDS reads and waits under the other's MFMAs) instead
+    // of 4 (64 x 128): 256-channel generator convs 76.9 / 108.5 / 145.5 -> 58.6 / 89.6 / 127.2 us at 3 / 7 / 11 taps
+    // (tools/conv_probe.py), generator 10.37 -> 10.05 ms per bench step; GSV_CONV_TILE_WAVES=4 restores round 2's geometry
+    static const int tile_waves = getenv("GSV_CONV_TILE_WAVES") ? atoi(getenv("GSV_CONV_TILE_WAVES")) : 8;
+    if (sizeof(T) == 2 && tile_waves == 8) {
+      if (a.Cin >= CCBIG && fits<T, 128, CCBIG>(rows)) return launch_inst<T, 2, 2, 2, 4, CCBIG, false>(a, rows, lo, s);
+      if (a.Cin >= CCBIG / 2 && fits<T, 128, CCBIG / 2>(rows)) return launch_inst<T, 2, 2, 2, 4, CCBIG / 2, false>(a, rows, lo, s);
+    }
     if (a.Cin >= CCBIG && fits<T, 128, CCBIG>(rows)) return launch_inst<T, 2, 4, 2, 2, CCBIG, false>(a, rows, lo, s);
     if (a.Cin >= CCBIG / 2 && fits<T, 128, CCBIG / 2>(rows)) return launch_inst<T, 2, 4, 2, 2, CCBIG / 2, false>(a, rows, lo, s);
     return 1;
