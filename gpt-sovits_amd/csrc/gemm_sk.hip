@@ -167,12 +167,20 @@ __global__ __launch_bounds__(256) void gemm_sk_f16_kernel(ConvArgs a) {
 // 8x fewer cache lines touched per flop than the streaming kernel above (whole 512-byte row segments, each fragment
 // read by two waves from LDS), and the latency of a dependent global -> LDS -> MFMA step is amortised over a 256-wide K
 // slab (64 KB per step, two register sets + two LDS buffers = the next TWO slabs in flight under the current one).
-struct Slab { h8 a[8], b[8]; };
+// SLAB = K halfs staged per pipeline stage: 256 (64 KB per buffer, 128 KB in all: ONE workgroup per CU) or 128 (32 KB per buffer,
+// 64 KB in all: TWO workgroups per CU -- one's loads and barriers under the other's MFMAs, and 480-workgroup grids (the DiT's FF1
+// at T = 934) run in one round instead of two)
+template <int SLAB> struct SlabT { h8 a[SLAB / 32], b[SLAB / 32]; };
 
-template <bool WNT>
+template <bool WNT, int SLAB>
 __global__ __launch_bounds__(256) void gemm_t64_f16_kernel(ConvArgs a) {
   constexpr int LDO = 68;
-  extern __shared__ float os[];                     // 2 x [A: 64 rows x 512 B][B: 64 rows x 512 B]; epilogue: [64 t][LDO] fp32
+  constexpr int RB = SLAB * 2;                      // bytes per staged row
+  constexpr int PPR = RB / 16;                      // 16-byte pieces per row (32 / 16)
+  constexpr int RPP = 256 / PPR;                    // rows per staging pass (8 / 16)
+  constexpr int NP = 64 / RPP;                      // passes = vectors per thread per operand (8 / 4)
+  constexpr int OPB = 64 * RB;                      // bytes per operand per buffer
+  extern __shared__ float os[];                     // 2 x [A: 64 rows x RB][B: 64 rows x RB]; epilogue: [64 t][LDO] fp32
   char* lds = (char*)os;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -181,41 +189,42 @@ __global__ __launch_bounds__(256) void gemm_t64_f16_kernel(ConvArgs a) {
   const int t0 = (vid % gridDim.x) * 64, c0 = (vid / gridDim.x) * 64;
   const _Float16* __restrict__ x = (const _Float16*)a.x;
   const _Float16* __restrict__ w = (const _Float16*)a.w;
-  // staging: thread -> 16-byte piece (tid & 31) of rows (tid >> 5) + 8 i; LDS slot = piece ^ (row & 15) (conflict-free
+  // staging: thread -> 16-byte piece (tid % PPR) of rows (tid / PPR) + RPP i; LDS slot = piece ^ (row & 15) (conflict-free
   // fragment reads for 16 consecutive rows, conflict-free lane-contiguous writes)
-  const int sp = tid & 31, sr = tid >> 5;
-  const _Float16* wp[8];
-  const _Float16* xp[8];
-  int woff[8];
+  const int sp = tid % PPR, sr = tid / PPR;
+  const _Float16* wp[NP];
+  const _Float16* xp[NP];
+  int woff[NP];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = 8 * i + sr;
+  for (int i = 0; i < NP; ++i) {
+    const int row = RPP * i + sr;
     wp[i] = w + (long long)min(c0 + row, a.Cout - 1) * a.ldw + 8 * sp;
     xp[i] = x + (long long)min(t0 + row, a.T_in - 1) * a.ldx + 8 * sp;
-    woff[i] = row * 512 + ((sp ^ (row & 15)) << 4);
+    woff[i] = row * RB + ((sp ^ (row & 15)) << 4);
   }
+  typedef SlabT<SLAB> Slab;
   auto load = [&](Slab& f, int c) {
-    const int k0 = c << 8;
+    const int k0 = c * SLAB;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NP; ++i) {
       f.a[i] = WNT ? __builtin_nontemporal_load((const h8*)(wp[i] + k0)) : *(const h8*)(wp[i] + k0);
       f.b[i] = *(const h8*)(xp[i] + k0);
     }
   };
   auto stage = [&](const Slab& f, int buf) {
-    char* base = lds + buf * 65536;
+    char* base = lds + buf * 2 * OPB;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { *(h8*)(base + woff[i]) = f.a[i]; *(h8*)(base + 32768 + woff[i]) = f.b[i]; }
+    for (int i = 0; i < NP; ++i) { *(h8*)(base + woff[i]) = f.a[i]; *(h8*)(base + OPB + woff[i]) = f.b[i]; }
   };
   f16v acc0, acc1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
   const int rowA = wm * 32 + r, rowB = wn * 32 + r;
   auto compute = [&](int buf) {
-    const char* pa = lds + buf * 65536 + rowA * 512;
-    const char* pb = lds + buf * 65536 + 32768 + rowB * 512;
+    const char* pa = lds + buf * 2 * OPB + rowA * RB;
+    const char* pb = lds + buf * 2 * OPB + OPB + rowB * RB;
 #pragma unroll
-    for (int j = 0; j < 16; j += 2) {
+    for (int j = 0; j < SLAB / 16; j += 2) {
       const h8 fa0 = *(const h8*)(pa + ((((2 * j + h)) ^ (rowA & 15)) << 4));
       const h8 fb0 = *(const h8*)(pb + ((((2 * j + h)) ^ (rowB & 15)) << 4));
       const h8 fa1 = *(const h8*)(pa + ((((2 * j + 2 + h)) ^ (rowA & 15)) << 4));
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256) void gemm_t64_f16_kernel(ConvArgs a) {
       mma32(acc1, fa1, fb1);
     }
   };
-  const int nslab = a.Cin >> 8, last = nslab - 1;    // even (Cin % 512 == 0, checked by the launcher)
+  const int nslab = a.Cin / SLAB, last = nslab - 1;    // even (Cin % (2 SLAB) == 0, checked by the launcher)
   Slab s0, s1;
   load(s0, 0);
   load(s1, min(1, last));
@@ -283,16 +292,24 @@ int launch_gemm_sk(int dtype, const ConvArgs& a, hipStream_t s) {
   if (tiles128 >= max_tiles || a.T_virt > 2048) return 1;
   static const bool t64 = !(getenv("GSV_GEMM_T64") && getenv("GSV_GEMM_T64")[0] == '0');   // A/B switch
   if (t64 && a.Cin % 512 == 0) {
+    // 128-half stages (two workgroups per CU) by default; GSV_T64_SLAB=256 restores round 2's single resident workgroup
+    static const int slab = getenv("GSV_T64_SLAB") ? atoi(getenv("GSV_T64_SLAB")) : 128;
     static bool attr64 = false;
-    const size_t lds64 = 131072;
     if (!attr64) {
-      GSV_HIP(hipFuncSetAttribute((const void*)gemm_t64_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
-      GSV_HIP(hipFuncSetAttribute((const void*)gemm_t64_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
+      GSV_HIP(hipFuncSetAttribute((const void*)gemm_t64_f16_kernel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+      GSV_HIP(hipFuncSetAttribute((const void*)gemm_t64_f16_kernel<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+      GSV_HIP(hipFuncSetAttribute((const void*)gemm_t64_f16_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+      GSV_HIP(hipFuncSetAttribute((const void*)gemm_t64_f16_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
       attr64 = true;
     }
     dim3 grid64(cdiv(a.T_virt, 64), cdiv(a.Cout, 64));
-    if (a.w_nt) hipLaunchKernelGGL(gemm_t64_f16_kernel<true>, grid64, dim3(256), lds64, s, a);
-    else hipLaunchKernelGGL(gemm_t64_f16_kernel<false>, grid64, dim3(256), lds64, s, a);
+    if (slab == 128) {
+      if (a.w_nt) hipLaunchKernelGGL((gemm_t64_f16_kernel<true, 128>), grid64, dim3(256), 65536, s, a);
+      else hipLaunchKernelGGL((gemm_t64_f16_kernel<false, 128>), grid64, dim3(256), 65536, s, a);
+    } else {
+      if (a.w_nt) hipLaunchKernelGGL((gemm_t64_f16_kernel<true, 256>), grid64, dim3(256), 131072, s, a);
+      else hipLaunchKernelGGL((gemm_t64_f16_kernel<false, 256>), grid64, dim3(256), 131072, s, a);
+    }
     GSV_HIP(hipGetLastError());
     return 0;
   }
