@@ -400,13 +400,14 @@ int launch_flash_rel96_f16(const void* q, int ldq, const void* k, int ldk, const
 
 // q / k: [T][ld] with head h at columns h*64..; v likewise; vt_buf: heads * 64 * ceil32(T) halfs of scratch
 int launch_flash_attn64_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldvv, void* vt_buf, int T, int heads,
-                            float scale, void* out, int ldo, hipStream_t s, const float* rope_cs, int rope_half) {
+                            float scale, void* out, int ldo, hipStream_t s, const float* rope_cs, int rope_half, bool vt_ready) {
   GSV_REQUIRE(T >= 1 && heads >= 1, "flash_attn: empty problem");
   GSV_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)out % 8) == 0,
               "flash_attn: operands must be 16-byte aligned with leading dims multiple of 8");
   const int ldv = (T + 31) / 32 * 32;
-  hipLaunchKernelGGL(vt_kernel, dim3(ldv / 32, 2, heads + (rope_cs ? 1 : 0)), dim3(256), 0, s, (const _Float16*)v, ldvv, T, ldv,
-                     (_Float16*)vt_buf, heads, (_Float16*)const_cast<void*>(q), ldq, (_Float16*)const_cast<void*>(k), ldk, rope_cs, rope_half);
+  if (!vt_ready)
+    hipLaunchKernelGGL(vt_kernel, dim3(ldv / 32, 2, heads + (rope_cs ? 1 : 0)), dim3(256), 0, s, (const _Float16*)v, ldvv, T, ldv,
+                       (_Float16*)vt_buf, heads, (_Float16*)const_cast<void*>(q), ldq, (_Float16*)const_cast<void*>(k), ldk, rope_cs, rope_half);
   static const int qt_env = getenv("GSV_FLASH_QT") ? atoi(getenv("GSV_FLASH_QT")) : 0;     // A/B switch
   // more query tiles per workgroup = fewer K / V fragment loads per query, but fewer workgroups: keep >= ~1 per CU
   int qt = qt_env ? qt_env : ((long long)cdiv(T, 64) * heads >= 200 ? 4 : ((long long)cdiv(T, 32) * heads >= 200 ? 2 : 1));

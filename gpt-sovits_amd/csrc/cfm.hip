@@ -400,13 +400,26 @@ int cfm_infer_batch(gsv_cfm* c, hipStream_t s, const float* mods, const float* m
       const float* m = mods + ((size_t)l * N + step) * 6 * D;   // shift_a, scale_a, gate_a, shift_m, scale_m, gate_m
       GSV_RC(launch_ln_mod<T>(hb, m + D, m, R, D, nrm, s));
       const int wnt = l >= resident ? 1 : 0;
-      { ConvOpt oq; oq.w_nt = wnt; GSV_RC(conv(h, s, blk.qkv, nrm, D, R, qkv, R, oq)); }
+      // OPT-IN (GSV_CFM_QKV_FUSE=1): the QKV GEMM's epilogue applies the rotary embedding and stores V transposed, one launch per
+      // block less.  Measured at the v3 shape (T = 934): 2.472 vs 2.474 ms per Euler step -- no gain (the 5 us launch it removes
+      // comes back as a heavier epilogue of the V column tiles on a grid that fills 75 % of the CUs), so the separate launch,
+      // which the parity tests cover at every shape, stays the default
+      static const bool want_fuse = getenv("GSV_CFM_QKV_FUSE") != nullptr;
+      const bool fuse_qkv = flash && B == 1 && R >= 512 && want_fuse && (2 * inner) % 128 == 0;
+      {
+        ConvOpt oq; oq.w_nt = wnt;
+        if (fuse_qkv) {
+          oq.vt_out = vtb; oq.vt_col0 = 2 * inner; oq.vt_ld = (Tn + 31) / 32 * 32;
+          oq.rope_cs = cs; oq.rope_half = half; oq.rope_q0 = 0; oq.rope_k0 = inner;
+        }
+        GSV_RC(conv(h, s, blk.qkv, nrm, D, R, qkv, R, oq));
+      }
       if (!flash) CFM_LAUNCH(cfm_rope_kernel<T>, R * half * 2, (T*)qkv, 3 * inner, inner, R, Tn, half, cs);   // else inside the V^T launch
       for (int b = 0; b < B; ++b) {
         const T* qb = (const T*)rows(qkv, b, 3 * inner);
         if (flash) {
           GSV_RC(launch_flash_attn64_f16(qb, 3 * inner, (const _Float16*)qb + inner, 3 * inner, (const _Float16*)qb + 2 * inner, 3 * inner,
-                                         vtb, Tn, g.heads, att_scale, rows(ao, b, inner), inner, s, cs, half));
+                                         vtb, Tn, g.heads, att_scale, rows(ao, b, inner), inner, s, cs, half, fuse_qkv));
         } else {
           GSV_RC(attention(h, s, qb, 3 * inner, 0, qb, 3 * inner, inner, 2 * inner, Tn, Tn, g.heads, g.dim_head, att_scale, nullptr,
                            nullptr, rows(ao, b, inner), inner));

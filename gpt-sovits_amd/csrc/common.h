@@ -159,6 +159,14 @@ struct ConvArgs {
   int xcd_order = 0;                         // set by the launcher: 1 = decode tile ids through xcd_virtual_id
   int w_nt = 0;                              // weights are loaded non-temporal (streamed once per step: keep them out of the
                                              // Infinity Cache so that OTHER layers' weights stay resident), GEMM paths only
+  // DiT QKV projection (gemm_lds_kernel, fp16 only): the epilogue of the q / k column tiles applies the rotary embedding to the
+  // first 2 * rope_half channels of q (columns rope_q0 ..) and k (rope_k0 ..), and the v column tiles (columns >= vt_col0) are
+  // stored TRANSPOSED as vt[(col - vt_col0)][t] (leading dim vt_ld >= T_virt rounded up to 32, zeros beyond T_virt) instead of
+  // into y -- what attn.hip's vt_kernel did in a launch of its own
+  void* vt_out = nullptr;
+  int vt_col0 = 0, vt_ld = 0;
+  const float* rope_cs = nullptr;            // [T][rope_half][2] cos, sin
+  int rope_half = 0, rope_q0 = 0, rope_k0 = 0;
 };
 int launch_conv_gemm(int dtype, const ConvArgs& a, hipStream_t s);
 // split-K-in-workgroup streaming GEMM for under-filled grids (gemm_sk.hip): 0 = launched, 1 = not eligible, <0 = error
@@ -186,7 +194,8 @@ int launch_conv_pair(const ConvPairArgs& a, hipStream_t s);
 // fused attention, fp16, head dim 64 (attn.hip); vt_buf: heads * 64 * ceil32(T) halfs of scratch
 // rope_cs != null: rotate the first 2*rope_half channels of q and k in place first (cos|sin table [T][rope_half][2])
 int launch_flash_attn64_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* vt_buf, int T, int heads,
-                            float scale, void* out, int ldo, hipStream_t s, const float* rope_cs = nullptr, int rope_half = 0);
+                            float scale, void* out, int ldo, hipStream_t s, const float* rope_cs = nullptr, int rope_half = 0,
+                            bool vt_ready = false);   // vt_ready: V^T (and the rotary embedding) already produced by the QKV GEMM's epilogue
 
 // enc_p self-attention with window-4 relative positions, fp16, head dim 96 (attn.hip)
 int launch_flash_rel96_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* vt_buf, int T, int heads,

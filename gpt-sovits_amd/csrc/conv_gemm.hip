@@ -221,6 +221,7 @@ int launch_conv_gemm(int dtype, const ConvArgs& a_in, hipStream_t s) {
     const int rc = launch_gemm_sk(dtype, a, s);
     if (rc <= 0) return rc;
   }
+  if (no_lds && (a.vt_out || a.rope_cs)) { set_error("conv_gemm: fused QKV epilogue needs the LDS GEMM path"); return GSV_ERR_ARG; }
   if (!no_lds) {
     int rc = launch_conv_wide(dtype, a, s);
     if (rc <= 0) return rc;

@@ -469,6 +469,28 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
         }
     }
     __syncthreads();
+    if constexpr (sizeof(T) == 2 && !RES) {
+      if (a.vt_out && cout0 >= a.vt_col0) {
+        // V column tile: stored transposed, vt[col][t] (what attn.hip's vt_kernel produced from y); item = (column, 4 steps)
+        constexpr int TG = PR / 4;                    // 4-step groups per pass
+#pragma unroll
+        for (int e = 0; e < NI; ++e) {
+          const int idx = tid + e * NT;
+          const int c = idx / TG, tg = idx - c * TG;
+          const int co = cout0 + c;
+          const int t = t0 + pass * PR + 4 * tg;
+          if (co >= a.Cout || t >= a.vt_ld) continue;
+          const float bz = a.bias ? a.bias[co] : 0.f;
+          T4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (t + j < a.T_virt) ? (T)((os[(size_t)(4 * tg + j) * LDO + c] + bz) * a.scale) : (T)0.f;
+          *(T4*)((T*)a.vt_out + (long long)(co - a.vt_col0) * a.vt_ld + t) = o;
+        }
+        continue;
+      }
+    }
+    const bool rope_here = sizeof(T) == 2 && a.rope_cs != nullptr &&
+                           ((ec >= a.rope_q0 && ec < a.rope_q0 + 2 * a.rope_half) || (ec >= a.rope_k0 && ec < a.rope_k0 + 2 * a.rope_half));
     // the activation code is tested once per pass, not per element (conv_wide.hip: ~50 scalar instructions per value otherwise)
     auto items = [&](auto act_tag) {
   #pragma unroll
@@ -486,6 +508,17 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
           u *= a.scale;
           u = post_act_c<decltype(act_tag)::value>(a.post_act, u);
           v[j] = u;
+        }
+        if (rope_here) {
+          // rotary embedding on the fp16-rounded values, as the separate kernel applied it to the stored projection
+          const int p0 = (ec - (ec >= a.rope_k0 ? a.rope_k0 : a.rope_q0)) >> 1;
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) {
+            const float cs = a.rope_cs[((long long)t * a.rope_half + p0 + pp) * 2], sn = a.rope_cs[((long long)t * a.rope_half + p0 + pp) * 2 + 1];
+            const float x0 = (float)(T)v[2 * pp], x1 = (float)(T)v[2 * pp + 1];
+            v[2 * pp] = x0 * cs - x1 * sn;
+            v[2 * pp + 1] = x1 * cs + x0 * sn;
+          }
         }
         const long long yoff = ybase + (long long)t * a.ldy + a.y_col0 + ec;
         const bool vec = vec_ok && env == 4 && ((ybase & 3) == 0);
@@ -507,6 +540,11 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
 template <typename T> static int try_launch_gemm(const ConvArgs& a, hipStream_t s) {
   constexpr int G = DT<T>::G;
   constexpr int BK = 64 * 2 / (int)sizeof(T);
+  if ((a.vt_out || a.rope_cs) && (sizeof(T) != 2 || a.res || a.Z != 1 || a.vt_col0 % 128 != 0 || a.vt_ld % 4 != 0 || a.rope_q0 % 4 != 0 ||
+                                  a.rope_k0 % 4 != 0 || a.out_f32)) {
+    set_error("gemm: fused rotary / V^T epilogue needs fp16, no residual, tile-aligned V columns");
+    return GSV_ERR_ARG;
+  }
   if (a.taps != 1 || a.stride != 1 || a.ups_u > 0 || a.accumulate || a.pad != 0) return 1;
   if (a.T_virt < 512 || a.Cout < 96 || a.Cin % (2 * G) != 0 || a.Cin < BK) return 1;
   if (a.Z > 1 && ((a.xz % G) || (a.wz % G) || a.res)) return 1;      // batched: head slices must stay 16-byte aligned
@@ -872,6 +910,7 @@ int launch_conv_lds(int dtype, const ConvArgs& a, hipStream_t s) {
   if (dtype == GSV_F16) rc = try_launch_gemm<_Float16>(a, s);
   else if (dtype == GSV_F32) rc = try_launch_gemm<float>(a, s);
   if (rc != 1) return rc;
+  if (a.vt_out || a.rope_cs) { set_error("gemm: the fused rotary / V^T epilogue exists in gemm_lds_kernel only (shape not eligible)"); return GSV_ERR_ARG; }
   if (dtype == GSV_F16) return try_launch<_Float16>(a, s);
   if (dtype == GSV_F32) return try_launch<float>(a, s);
   return 1;

@@ -69,6 +69,9 @@ struct ConvOpt {
   const float* gate = nullptr;   // per-output-channel gate: y = ((W x + b) * gate + res) * scale
   int w_nt = 0;                  // stream the weights non-temporal (ConvArgs::w_nt)
   int w_row0 = 0, cout = -1;   // use a row slice of the weight matrix
+  // DiT QKV projection: rotary embedding + transposed V from the GEMM's epilogue (ConvArgs::vt_out ...)
+  void* vt_out = nullptr; int vt_col0 = 0, vt_ld = 0;
+  const float* rope_cs = nullptr; int rope_half = 0, rope_q0 = 0, rope_k0 = 0;
 };
 
 #define GSV_DISPATCH(h, call_f16, call_f32) \

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void gemm_t64_f16_kernel(ConvArgs a) {
 // 0 = launched, 1 = not eligible, < 0 error
 int launch_gemm_sk(int dtype, const ConvArgs& a, hipStream_t s) {
   static const bool off = getenv("GSV_NO_GEMM_SK") != nullptr;     // A/B switch for profiling
-  if (off || dtype != GSV_F16) return 1;
+  if (off || dtype != GSV_F16 || a.vt_out || a.rope_cs) return 1;     // fused QKV epilogues live in gemm_lds_kernel
   if (a.taps != 1 || a.stride != 1 || a.ups_u > 0 || a.accumulate || a.pad != 0 || a.Z != 1 || a.pre_act != ACT_NONE) return 1;
   if (a.Cin % 64 != 0 || a.Cin < 256 || a.Cout < 64) return 1;
   if (a.ldx % 8 != 0 || a.ldw % 8 != 0 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return 1;

@@ -523,6 +523,8 @@ int conv(gsv_vits* h, hipStream_t s, const Conv& c, const void* x, int ldx, int 
   }
   a.ldr = o.ldr ? o.ldr : a.ldy;
   a.y_col0 = o.y_col0;
+  a.vt_out = o.vt_out; a.vt_col0 = o.vt_col0; a.vt_ld = o.vt_ld;
+  a.rope_cs = o.rope_cs; a.rope_half = o.rope_half; a.rope_q0 = o.rope_q0; a.rope_k0 = o.rope_k0;
   return launch_conv_gemm(h->dtype, a, s);
 }
 
