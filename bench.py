@@ -17,9 +17,12 @@ the ranks take from a work queue (strong scaling over the job, `"scaling": "stro
 Prints ONE JSON line (rank 0).  `roofline` = the kernel with the largest share of GPU time: the persistent AR decode engine
 `t2s_mega_kernel` (one launch = all decode steps after step 0 of one batch; HBM-bound): algorithmic
 bytes of its steps / its duration from HIP events on the engine's stream (gsv_t2s_decode_info), measured on the LAST timed
-step; `roofline_step` / `roofline_prefill` / `roofline_generator` put the other stages against their bounds, `fp32` repeats a
-few steps with the parity dtype, `v3` times BASELINE configs[3] (one 934-frame chunk: 32 Euler steps of the DiT + BigVGAN),
-`cold_prompt` the reference-audio front-end (WAV -> HuBERT -> codes, spectrogram) that precedes a first utterance.
+step; `roofline_step` / `roofline_prefill` / `roofline_generator` put the other stages against their bounds; `total_1024` /
+`total_1024_b128` run BASELINE configs[2]'s 1024 utterances on this one GPU (batches of 32 / of 128 = one persistent AR launch
+per batch), `long_form` streams configs[4]'s 140 sentences in reading order (time to the first fragment; `first_batch_8`: the
+same with a first batch of 8 sentences), `fp32` repeats a few steps with the parity dtype, `v3` times BASELINE configs[3] (one
+934-frame chunk: 32 Euler steps of the DiT + BigVGAN), `cold_prompt` the reference-audio front-end (WAV -> HuBERT -> codes,
+spectrogram) that precedes a first utterance.
 `cpu_baseline` = the oracle (CPU restatement, kind "port") on a bounded sample of the same workload on this box's host cores.
 """
 from __future__ import annotations

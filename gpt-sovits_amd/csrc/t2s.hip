@@ -982,7 +982,7 @@ struct gsv_t2s {
   // current batch
   int B = 0, P = 0;
   int max_kv0 = 0;          // longest row's cached positions after prefill (host copy: bounds the decode budget)
-  // persistent decode engine (t2s_mega.hip): fp16, v1/v2 shape, B <= 32; the launch-per-phase step stays as the
+  // persistent decode engine (t2s_mega.hip): fp16, v1/v2 shape, B <= 128; the launch-per-phase step stays as the
   // fp32 / other-shape path and behind GSV_T2S_NO_MEGA=1 for A/B
   MegaState mega;
   hipEvent_t mega_ev[2] = {nullptr, nullptr};

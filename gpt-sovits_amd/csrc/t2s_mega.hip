@@ -27,6 +27,12 @@
 //     seven times; the hops are sc1 and do not care.  Correctness never depends on the placement.
 //   * logits are split over the members too; row r of a group is sampled by member r (one wave, sample_core of
 //     t2s_sample.h), which also emits the next input embedding: the step's tail is two more hops.
+//   * (round 3) more than 32 rows: a group serves up to four QUADS of rows, phase by phase one after the other with the weight
+//     slices it already holds; the comm waves sweep quad i + 1 into a second copy of the operand image while the compute
+//     waves work on quad i (comm_role_pipe / compute_role_pipe, MODE 2).  The step is latency-bound, so rows are added in
+//     time, not in tile width: 128 rows cost 0.79 ms per step against 4 x 0.30.
+//   * weight slices are loaded with the DEFAULT cache policy (the 8 same-slice workgroups of an XCD share one L2 fill), K/V
+//     non-temporal (read once per step; keeps the weights in the Infinity Cache).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>

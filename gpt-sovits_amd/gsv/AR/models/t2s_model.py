@@ -263,7 +263,7 @@ class Text2SemanticDecoder:
     # ---- decode-engine selection / report -------------------------------------------
     def set_mega(self, on: bool):
         """A/B switch: False makes later calls use the launch-per-phase decode step instead of the persistent engine
-        (csrc/t2s_mega.hip; fp16, v1/v2 shape, batch <= 32)."""
+        (csrc/t2s_mega.hip; fp16, v1/v2 shape, batch <= 128 in one launch)."""
         _lib.check(_lib.lib().gsv_t2s_set_mega(self._h, int(bool(on))), "gsv_t2s_set_mega")
 
     def debug_stall(self, member: int):

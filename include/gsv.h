@@ -92,7 +92,7 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
                    int32_t* out_tokens, int32_t* out_len, int* steps_run, gsv_stream_t stream);
 
 /* How the last gsv_t2s_decode call ran: mode 1 = the persistent engine (csrc/t2s_mega.hip: fp16, d=512/16 heads/FFN 2048,
- * B <= 32; all steps after step 0 in ONE launch, hand-offs on the chip), mode 0 = one hipGraph of 122 launches per step
+ * B <= 128 -- up to four quads of rows per row group, B <= 32 is one quad; all steps after step 0 in ONE launch, hand-offs on the chip), mode 0 = one hipGraph of 122 launches per step
  * (fp32, other shapes, GSV_T2S_NO_MEGA=1, or a device on which the engine's 256 workgroups are not co-resident);
  * device_ms = HIP-event time of the persistent launch, steps = decode steps it covered (mode 1 only). */
 int gsv_t2s_decode_info(gsv_t2s_t* h, int* mode, float* device_ms, int* steps);
