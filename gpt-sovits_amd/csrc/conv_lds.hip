@@ -854,8 +854,15 @@ template <typename T> static int try_launch(const ConvArgs& a, hipStream_t s) {
     static const bool no_half = getenv("GSV_CONV_NO_HALF_TILE") != nullptr;      // A/B switch
     const long long wgs256 = (long long)cdiv(a.T_virt, 256) * cdiv(a.Cout, 128);
     static const bool half_always = getenv("GSV_CONV_HALF_ALWAYS") != nullptr;    // experiment switch
+    // 8 waves (64 channels x 32 steps per wave) for the half tiles too: these grids have fewer workgroups than CUs, so a
+    // workgroup is alone on its CU -- SoVITS device time 13.62 -> 13.2 ms per bench step; GSV_CONV_HALF_WAVES=4 restores
+    static const int half_waves = getenv("GSV_CONV_HALF_WAVES") ? atoi(getenv("GSV_CONV_HALF_WAVES")) : 8;
     if (!no_half && (wgs256 < 192 || half_always)) {
       const int rows128 = 128 + span;
+      if (sizeof(T) == 2 && half_waves == 8) {
+        if (a.Cin >= CCBIG && fits<T, 128, CCBIG>(rows128)) return launch_inst<T, 2, 1, 2, 4, CCBIG, false>(a, rows128, lo, s);
+        if (a.Cin >= CCBIG / 2 && fits<T, 128, CCBIG / 2>(rows128)) return launch_inst<T, 2, 1, 2, 4, CCBIG / 2, false>(a, rows128, lo, s);
+      }
       if (a.Cin >= CCBIG && fits<T, 128, CCBIG>(rows128)) return launch_inst<T, 2, 2, 2, 2, CCBIG, false>(a, rows128, lo, s);
       if (a.Cin >= CCBIG / 2 && fits<T, 128, CCBIG / 2>(rows128)) return launch_inst<T, 2, 2, 2, 2, CCBIG / 2, false>(a, rows128, lo, s);
     }
