@@ -330,16 +330,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
 // operands double-buffered in LDS through registers: the loads of K-chunk c+1 are in flight while
 // chunk c feeds 16 MFMAs per wave, one barrier per chunk; ~74 KB of LDS -> two workgroups per CU.
 // ---------------------------------------------------------------------------------------
-template <typename T, bool RES, bool WNT = false>
-__global__ __launch_bounds__(256) void gemm_lds_kernel(ConvArgs a) {
+// NW = waves per workgroup: 4 (64 x 64 outputs per wave; two workgroups per CU when the grid is large enough) or 8 (64 x 32 per
+// wave: for grids with fewer tiles than CUs, where a workgroup is alone on its CU and a second wave per SIMD hides its stalls)
+template <typename T, bool RES, bool WNT = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_lds_kernel(ConvArgs a) {
   typedef typename FragL<T>::type F;
   constexpr int G = DT<T>::G, KC = 2 * G;
   constexpr int BK = 64 * 2 / (int)sizeof(T);        // 64 fp16 / 32 fp32 elements = 128 B per row
   constexpr int LDX = BK + G;
   constexpr int VPR = BK / G;                        // 8 vectors per row
-  constexpr int CT = 128, TT = 128, NT = 256;
-  constexpr int NLD = CT * VPR / NT;                 // vectors per thread per operand per chunk (4)
-  constexpr int TM = 2, TN = 2, WN = 2;
+  constexpr int CT = 128, TT = 128, NT = NW * 64;
+  constexpr int NLD = CT * VPR / NT;                 // vectors per thread per operand per chunk (4 / 2)
+  constexpr int TM = 2, TN = NW == 8 ? 1 : 2, WN = NW == 8 ? 4 : 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = (T*)smem;                                  // [2][TT][LDX]
   T* ws = xs + 2 * TT * LDX;                         // [2][CT][LDX]
@@ -562,22 +564,21 @@ template <typename T> static int try_launch_gemm(const ConvArgs& a, hipStream_t 
   // instead of once per column tile (tools/gemm_probe.py, GSV_GEMM_XCD=1 restores order 1).
   static const bool only1 = getenv("GSV_GEMM_XCD") && getenv("GSV_GEMM_XCD")[0] == '1';
   if (xcd && !only1 && (long long)a.T_virt > 2LL * a.Cout && (size_t)a.Cout * a.Cin * sizeof(T) <= (size_t)3 << 20) b.xcd_order = 2;
-  if (a.res) {
-    auto kern = gemm_lds_kernel<T, true>;
-    static bool set = false;
-    if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
-  } else if (a.w_nt) {
-    auto kern = gemm_lds_kernel<T, false, true>;
-    static bool set = false;
-    if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
-  } else {
-    auto kern = gemm_lds_kernel<T, false>;
-    static bool set = false;
-    if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
-  }
+  // 8 waves per workgroup where the grid has fewer tiles than the chip has CUs (prefill out-projection / FFN2: 180 tiles, the
+  // DiT's QKV: 192, enc_p 1 x 1 convs): the workgroup is alone on its CU; GSV_GEMM_WAVES=4 restores round 2's geometry
+  static const int gemm_waves = getenv("GSV_GEMM_WAVES") ? atoi(getenv("GSV_GEMM_WAVES")) : 8;
+  const bool w8 = sizeof(T) == 2 && gemm_waves == 8 && (long long)grid.x * grid.y * grid.z <= 256;
+#define GSV_GEMM_LAUNCH(R, NTW, W)                                                                                         \
+  do {                                                                                                                     \
+    auto kern = gemm_lds_kernel<T, R, NTW, W>;                                                                             \
+    static bool set = false;                                                                                               \
+    if (!set) { GSV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+    hipLaunchKernelGGL(kern, grid, dim3(W * 64), lds, s, b);                                                               \
+  } while (0)
+  if (a.res) { if (w8) GSV_GEMM_LAUNCH(true, false, 8); else GSV_GEMM_LAUNCH(true, false, 4); }
+  else if (a.w_nt) { if (w8) GSV_GEMM_LAUNCH(false, true, 8); else GSV_GEMM_LAUNCH(false, true, 4); }
+  else { if (w8) GSV_GEMM_LAUNCH(false, false, 8); else GSV_GEMM_LAUNCH(false, false, 4); }
+#undef GSV_GEMM_LAUNCH
   GSV_HIP(hipGetLastError());
   return GSV_OK;
 }
