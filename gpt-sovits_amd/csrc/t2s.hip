@@ -1191,8 +1191,7 @@ int gsv_t2s_finalize(gsv_t2s_t* h) {
         dst += ns[k];
       }
     }
-    m.ring = getenv("GSV_MEGA_RING") ? atoi(getenv("GSV_MEGA_RING")) : 1;           // hop buffer sets (t2s_mega.hip hop_slot); measured: 16 sets are 4 % slower than 1
-    if (m.ring < 1) m.ring = 1;
+    m.ring = 1;                                            // one hop buffer set (t2s_mega.hip hop_slot)
     m.hop_bytes = mega_hop_bytes(m.ring);
     GSV_RC(dev_alloc(h, (void**)&m.hop, m.hop_bytes));
     GSV_RC(dev_alloc(h, (void**)&m.err, 64));
@@ -1543,7 +1542,13 @@ int gsv_t2s_decode(gsv_t2s_t* h, const gsv_sampling_params* sp, const float* noi
       a.nsteps = budget - 1; a.map_shared = map_local ? 0 : map_mode;
       // bits 0-3: hops (A, B, C, D) that poll one granule per line first; bits 8-12: 16ths of the lines that may still be
       // missing when the full passes start
-      static const int hint_mask = getenv("GSV_MEGA_HINT") ? atoi(getenv("GSV_MEGA_HINT")) : (15 | (2 << 8) | (6 << 13));   // bits 13-15: poll every 2^n-th payload line (6: one line per row)   // bit 4 (two polls in flight): 3 % slower; bit 5 (payload through L2, needs GSV_MEGA_RING > 1): no gain
+      // bits 0-3: hops A-D poll ONE hint line before the full pass (hop B, 2 KB per row, is faster polled in full: 288 -> 284 us
+      // per step); bit 7: every member polls ANOTHER publisher's line instead of all 32 polling the row's last line (297 -> 288
+      // us); bits 8-12: miss threshold of sweep2's per-line hints (logits hop).  Measured and left off: bit 4 (sweep2: two polls
+      // in flight, 3 % slower), bit 5 (payload through L2, needs GSV_MEGA_RING > 1: no gain).  Tried in sweep_wide and removed
+      // again: several hint lines per row, polls in flight, one polling wave per workgroup, a slower pace, a wait before the
+      // first poll (+1 to +9 %, profiles/r03_ab_hint_spread.txt) -- the knobs themselves cost 2 % in scalar registers
+      static const int hint_mask = getenv("GSV_MEGA_HINT") ? atoi(getenv("GSV_MEGA_HINT")) : (13 | (1 << 7) | (2 << 8));
       a.hint_mask = hint_mask;
       a.ring = m.ring;
       m.launch_gen = (m.launch_gen + 1) & 2047;

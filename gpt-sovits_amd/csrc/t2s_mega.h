@@ -38,7 +38,7 @@ struct MegaArgs {
   int B, L, V, nsteps;
   unsigned long long* prof;       // optional [256 workgroups][8 waves][32] s_memtime stamps of one (step, layer); null = off
   int prof_step, prof_layer, prof_quad;
-  int hint_mask;                  // hops that poll one granule per line before the full pass: bit 0 A, 1 B, 2 C, 3 D; bit 4: two polls in flight; bits 8-12: miss threshold; bits 13-15: log2 of the hint line stride
+  int hint_mask;                  // hops that poll a hint line before the full pass: bit 0 A, 1 B, 2 C, 3 D; bit 4: two polls in flight (sweep2); bit 7: spread hint lines; bits 8-12: miss threshold (sweep2)
   int map_shared;                 // 1: workgroups reading the same weight slice share an XCD (default), 0: group = XCD
   int ring;                       // hop buffer sets used round-robin over (step, layer); > 1 enables L2-shared payload reads
   unsigned ep_base;               // launch generation << 20: epochs never repeat between launches (stale cached lines cannot match)

@@ -154,13 +154,10 @@ struct Ctx {
   int qd, Rtot;                       // current quad; rows of the group (all quads)
   gu64* hop;                    // this group's hop buffers of the current (step, layer) ring slot
   gu64* hop_base;               // slot 0
-  int ring, nlayer;             // ring slots; virtual layers per step (L + 1: the tail is one)
-  bool bulk_plain;              // payload read with plain (L2-allocating) loads after the sc1 hint polls
   gu32* err;
   int hint_miss16;              // hint phase ends when at most this many 16ths of the polled lines are still missing
   int hint_pipe;                // two hint polls in flight (GSV_MEGA_HINT bit 4)
-  int hint_stride;              // poll every n-th payload line (1, 2, 4, 8)
-  int hint_one;                 // one polling wave per workgroup (wave 0 polls for all rows, LDS word to the others)
+  int hint_spread;              // each member polls a different publisher's line
   unsigned long long* prof;     // this wave's 32 stamp slots or null
   bool prof_on;
 };
@@ -257,29 +254,6 @@ __device__ __forceinline__ bool sweep2(const Ctx& c, gu64* g0, gu64* g1, int nva
       }
     }
   }
-  if (hint && c.bulk_plain) {
-    // every line's last granule is there: read the payload through L2 (see hop_slot); the tags are still verified
-    const gu64* p0 = g0;
-    const gu64* p1 = g1 ? g1 : g0;
-    asm volatile("" : "+v"(p0), "+v"(p1) :: "memory");
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const int i = k * 64 + c.lane;
-      v0[k] = 0u; v1[k] = 0u;
-      if (i < nvalid) {
-        const u64 x = p0[i];
-        v0[k] = (unsigned)x;
-        ok &= (unsigned)(x >> 32) == epoch;
-        if (g1) {
-          const u64 y = p1[i];
-          v1[k] = (unsigned)y;
-          ok &= (unsigned)(y >> 32) == epoch;
-        }
-      }
-    }
-    if (__all(ok)) return true;
-  }
   for (unsigned spins = 0;; ++spins) {
     bool ok = true;
 #pragma unroll
@@ -340,40 +314,25 @@ template <> __device__ __forceinline__ void wide_loads<8>(const gu64* p0, u4v (&
                : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
                : "v"(p0), "v"(p1) : "memory");
 }
+// The hint line of a member (GSV_MEGA_HINT bit 7, the default): the last line of publisher (member + 16) % 32 -- ANOTHER
+// member's line, and a different one for every member of the group.  With every member polling the same line (round 2: the
+// last line of the row) 32 workgroups re-read one address while its publisher was trying to write it: 297 -> 288 us per step
+// when the polls are spread; two or four lines per member, polls in flight, slower paces all lose (profiles/r03_ab_hint_spread.txt).
+template <int NLINES>
+__device__ __forceinline__ int hint_line(const Ctx& c) {
+  return ((c.member + 16) & 31) * NLINES / 32 + (NLINES >= 64 ? 1 : 0);
+}
 // one wave, one row of NQ * 128 granules
 template <int NQ>
 __device__ __forceinline__ bool sweep_wide(const Ctx& c, gu64* g, unsigned epoch, u4v (&q)[NQ], unsigned code, bool hint) {
   constexpr int NLINES = NQ * 8;                       // 16 granules per 128-byte line
-  if (hint && c.hint_one) {
-    // ONE polling wave per workgroup (GSV_MEGA_HINT bit 6): wave 0 polls the hint granule of every row of the group (lane r ->
-    // row r, one request per poll instead of one per wave) and tells the other sweepers through an LDS word; they spin on LDS
-    lds_vint* flag = (lds_vint*)(unsigned)L_ST + 3 * ST_N + 3;
-    if (c.cw == 0) {
-      const gu64* gh = g + (NLINES - 1) * 16 + 15;       // this wave sweeps row 0: g is row 0's base
-      for (unsigned spins = 0;; ++spins) {
-        const bool miss = c.lane < c.R && (unsigned)(gload(const_cast<gu64*>(gh) + (size_t)c.lane * (NQ * 128)) >> 32) != epoch;
-        if (!__ballot(miss)) break;
-        if (spins > SPIN_MAX || *st_abort(c) || (spins & 1023u) == 1023u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
-          mega_fail(c.err, c.lane, epoch, code | 0x100u);
-          return false;
-        }
-        if (spins < 8) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
-      }
-      *flag = (int)epoch;
-    } else {
-      for (unsigned spins = 0; *flag != (int)epoch; ++spins) {
-        if (spins > (SPIN_MAX << 4) || *st_abort(c)) { mega_fail(c.err, c.lane, epoch, code | 0x200u); return false; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-  } else
-  if (hint) {                                          // as in sweep2: the last granule of every line first
+  if (hint) {
+    // ONE line per row is polled before the full pass (round 2 found every extra poll to cost: every 2nd, 4th, ... line, two
+    // polls in flight, one polling wave per workgroup were all measured and are gone from this loop)
+    const int ln = c.hint_spread ? hint_line<NLINES>(c) : NLINES - 1;
+    gu64* hp = g + ln * 16 + 15;
     for (unsigned spins = 0;; ++spins) {
-      // every hint_stride-th line only (GSV_MEGA_HINT bits 13-14): fewer requests per poll, a weaker hint
-      const int np = max(1, NLINES / c.hint_stride);
-      const int ln = min(min(c.lane, np - 1) * c.hint_stride + c.hint_stride - 1, NLINES - 1);
-      const bool miss = c.lane < np && (unsigned)(gload(g + ln * 16 + 15) >> 32) != epoch;
-      if (__popcll(__ballot(miss)) * 16 <= np * c.hint_miss16) break;
+      if ((unsigned)__builtin_amdgcn_readfirstlane((int)(gload(hp) >> 32)) == epoch) break;     // one address for the wave
       if (spins > SPIN_MAX || *st_abort(c) || (spins & 1023u) == 1023u && __hip_atomic_load(c.err, RLX_AGENT) != 0u) {
         mega_fail(c.err, c.lane, epoch, code | 0x100u);
         return false;
@@ -445,6 +404,41 @@ __device__ __forceinline__ void gemm_chunk(const Ctx& c, const h8 (&w)[NT * 4], 
   }
 }
 
+// ONE 16-column tile over the whole K = 512 by one wave: FFN1's four tiles are split over the compute waves by COLUMN, so
+// no partial sums meet in LDS (the split-K form cost a barrier + an LDS round trip + two idle waves per layer).  Four chains,
+// one per 128-wide K chunk, summed ((c0 + c1) + c2) + c3: the order of the split-K reduce this replaces, bit for bit.  The
+// operand fragments of k-step ks + 1 are in flight under the four MFMAs of k-step ks.
+__device__ __forceinline__ f4 gemm_tile_k512(const Ctx& c, const h8 (&w)[16], const _Float16* act, int ld) {
+  const int rowl = c.lane & 15, kg = c.lane >> 4;
+  const _Float16* bp = act + (rowl & (RMAX - 1)) * ld + 8 * kg;
+  f4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (f4){0.f, 0.f, 0.f, 0.f};
+  h8 bA[4], bB[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bA[j] = *(const h8*)(bp + 128 * j);
+#pragma unroll
+  for (int ks = 0; ks < 4; ks += 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bB[j] = *(const h8*)(bp + 128 * j + 32 * (ks + 1));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[4 * j + ks], bA[j], acc[j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 2 < 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bA[j] = *(const h8*)(bp + 128 * j + 32 * (ks + 2));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[4 * j + ks + 1], bB[j], acc[j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  f4 v = acc[0];
+  v += acc[1]; v += acc[2]; v += acc[3];
+  return v;
+}
+
 template <int N>
 __device__ __forceinline__ void wload(h8 (&dst)[N], const h8* src) {
 #pragma unroll
@@ -476,16 +470,14 @@ __device__ __forceinline__ void relaunder(Ctx& q) {
   q.tid_c = q.cw * 64 + q.lane;
 }
 
-// A/B option (GSV_MEGA_RING = n > 1, GSV_MEGA_HINT bit 5): hop buffers used round-robin over the virtual layers (24 layers + the
-// tail per step), so that a buffer comes up again only n layers later, when no L2 or L1 still holds its lines, and the payload
-// can be read with plain loads that ALLOCATE in L2 -- the 4 members of a group that share an XCD then fetch a line from the
-// memory side once instead of four times (the all-gather is 18 MB per layer of memory-side reads, as much as the K/V).  A stale
-// line that survived anyway fails the tag check (epochs never repeat, not even across launches: ep_base) and the reader falls
-// back to the sc1 sweep.  MEASURED on MI355X: 16 buffer sets alone cost 4 % (586-591 vs 566 us per step: the one 0.9 MB set
-// stays resident on the memory side, 14 MB of rotating lines do not), and the L2-shared payload read gains nothing on top.
-// Default: one set, sc1 payload reads.
+// ONE set of hop buffers: the epoch in every granule tells (step, layer) apart.  Round 2 tried a ring of 16 sets used
+// round-robin over the layers, so that the payload could be read with plain loads that allocate in L2 (the 4 members of a group
+// on one XCD would fetch a line from the memory side once instead of four times).  MEASURED on MI355X: 16 sets alone cost 4 %
+// (the one 0.9 MB set stays resident on the memory side, 14 MB of rotating lines do not), the L2-shared read gained nothing on
+// top, and the run-time modulo this function then needed in every phase cost more; the option is gone (round 3).
 __device__ __forceinline__ gu64* hop_slot(const Ctx& c, int s, int l) {
-  return c.hop_base + (size_t)((unsigned)(s * c.nlayer + l) % (unsigned)c.ring) * ((size_t)MG_GROUPS * HOP_GROUP_ALL) + (size_t)c.qd * HOP_GROUP;
+  (void)s; (void)l;
+  return c.hop_base + (size_t)c.qd * HOP_GROUP;
 }
 
 __device__ __forceinline__ bool group_done(const Ctx& c) {
@@ -744,7 +736,7 @@ __device__ __forceinline__ void kv_stage_store(const Ctx& q, int qd, int extra, 
 // the weights the compute waves already hold; each quad has its own hop buffers, so while a member works on quad q the other
 // members' publishes of quad q + 1 are already on their way: the hop latency that a single quad waits out four times per layer
 // is overlapped with the other quads' compute, and the weights are still streamed once per layer.
-template <bool MULTI>
+template <bool MULTI, bool PROF>
 __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, const StepParams& sp) {
   Ctx q = c0;
   unsigned char* smem = c0.smem;
@@ -774,7 +766,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         set_quad(q, qd);
         const int R = q.R;
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
+        q.prof_on = PROF && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
         MG_STAMP(q, 0);
         // ---- hop A: y of the previous layer (or the step's input embedding) -> LayerNorm -> XS / XRES
         {
@@ -839,7 +831,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         relaunder(q);
         set_quad(q, qd);
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
+        q.prof_on = PROF && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
         if (ra < q.R) {
           u4v qb[2];
           if (sweep_wide<2>(q, q.hop + HOP_B + ra * 256, ep0 + 4 * l + 2, qb, 3u, a.hint_mask & 2)) {
@@ -860,7 +852,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         relaunder(q);
         set_quad(q, qd);
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
+        q.prof_on = PROF && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
         if (ra < q.R) {
           u4v qc[4];
           if (sweep_wide<4>(q, q.hop + HOP_C + ra * 512, ep0 + 4 * l + 3, qc, 4u, a.hint_mask & 4)) ln_row_wide(q, ra, qc, gC, bC);
@@ -869,7 +861,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         MG_BAR();                                                          // B1
         if (*st_abort(q)) return;
         MG_STAMP(q, 10);
-        MG_BAR();                                                          // B2
+        if (MULTI) MG_BAR();                                               // B2 (sequential quads only: see compute_role)
         MG_STAMP(q, 11);
       }
       // ================= P4 of every quad: hop D (FFN hidden) -> HS
@@ -877,7 +869,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         relaunder(q);
         set_quad(q, qd);
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
+        q.prof_on = PROF && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
         if (ra < q.R) {
           u4v qd8[8];
           if (sweep_wide<8>(q, q.hop + HOP_D + ra * 1024, ep0 + 4 * l + 4, qd8, 5u, a.hint_mask & 8)) {
@@ -914,7 +906,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
   }
 }
 
-template <bool MULTI>
+template <bool MULTI, bool PROF>
 __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
   Ctx q = c0;
   unsigned char* smem = c0.smem;
@@ -970,7 +962,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         set_quad(q, qd);
         const int R = q.R;
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && first;
+        q.prof_on = PROF && s == a.prof_step && l == a.prof_layer && first;
         MG_STAMP(q, 0);
         // lane j < 24 of every wave reduces 4 values of q | k | v of the wave's OWN attention row (see after B2)
         const int rj_which = (q.lane >> 3) % 3, rj_e = 4 * (q.lane & 7);
@@ -1057,7 +1049,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         set_quad(q, qd);
         const int R = q.R;
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && first;
+        q.prof_on = PROF && s == a.prof_step && l == a.prof_layer && first;
         const f4 p_bias = *(const f4*)(lp + FP_OUTB + 16 * q.member + 4 * (q.lane >> 4));
         MG_STAMP(q, 11);
         MG_BAR();                                                          // B1: AT holds the attention output
@@ -1103,41 +1095,34 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         set_quad(q, qd);
         const int R = q.R;
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && first;
-        const f4 p_bias = *(const f4*)(lp + FP_B1 + 64 * q.member + 32 * (q.cw & 1) + 4 * (q.lane >> 4));       // tiles 2 (cw & 1), +1
-        const f4 p_bias2 = *(const f4*)(lp + FP_B1 + 64 * q.member + 32 * (q.cw & 1) + 16 + 4 * (q.lane >> 4));
+        q.prof_on = PROF && s == a.prof_step && l == a.prof_layer && first;
+        const f4 p_bias = *(const f4*)(lp + FP_B1 + 64 * q.member + 16 * q.cw + 4 * (q.lane >> 4));       // tile cw of the member's four
         MG_STAMP(q, 15);
         MG_BAR();                                                          // B1: XS / XRES hold LN1(y1)
         if (*st_abort(q)) return;
         MG_STAMP(q, 16);
         wload(wD, pm_src(l, WI_P2 + WI_P3));
-        gemm_chunk<4>(q, wC, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 4);
+        f4 v = gemm_tile_k512(q, wC, (const _Float16*)(smem + L_XS), XS_LD);
         if (MULTI && q.cw == 2 && (q.lane & 15) < R)                       // FFN2's residual operand of this quad
           *rs_slot(1, qd) = *(const f4*)((const float*)(smem + L_XRES) + (q.lane & 15) * D + 16 * q.member + 4 * (q.lane >> 4));
         MG_STAMP(q, 17);
-        MG_BAR();                                                          // B2
+        // sequential quads: the comm waves overwrite XS with the next quad's rows right after this barrier.  One quad: none
+        // needed -- the next writer of XS is hop A of the next layer, two workgroup barriers away
+        if (MULTI) MG_BAR();                                               // B2
         MG_STAMP(q, 18);
-        if (q.cw < 2) {
-          // waves 0 and 1 reduce tiles {0, 1} and {2, 3}: 32 columns = 16 half-pair granules = one 128-B line per row
-          const f4* red = (const f4*)(smem + L_RED);
+        {
+          // every wave publishes its own tile: 16 columns = 8 half-pair granules = 64 contiguous bytes per row, the rows of
+          // the quad by one store instruction (transposed through the wave's own LDS patch: lane = row * 8 + granule)
           const int r = q.lane & 15;
-          unsigned* stage = (unsigned*)(smem + L_STAGE) + q.cw * 256;
+          unsigned* stage = (unsigned*)(smem + L_STAGE) + q.cw * 64;
+          v += p_bias;
           if (r < R) {
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-              const int tile = 2 * q.cw + tt;
-              const f4 v0 = red[red_idx(0 * 4 + tile, q.lane)], v1 = red[red_idx(1 * 4 + tile, q.lane)],
-                       v2 = red[red_idx(2 * 4 + tile, q.lane)], v3 = red[red_idx(3 * 4 + tile, q.lane)];
-              f4 v = v0;
-              v += v1; v += v2; v += v3;
-              v += tt == 0 ? p_bias : p_bias2;
-              const int w0 = r * 16 + tt * 8 + 2 * (q.lane >> 4);
-              stage[w0] = pack_h2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
-              stage[w0 + 1] = pack_h2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-            }
+            const int w0 = r * 8 + 2 * (q.lane >> 4);
+            stage[w0] = pack_h2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+            stage[w0 + 1] = pack_h2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
           }
-          if (q.lane < R * 16)
-            gstore(q.hop + HOP_D + (q.lane >> 4) * 1024 + 32 * q.member + 16 * q.cw + (q.lane & 15), ep0 + 4 * l + 4, stage[q.lane]);
+          if (q.lane < R * 8)
+            gstore(q.hop + HOP_D + (q.lane >> 3) * 1024 + 32 * q.member + 8 * q.cw + (q.lane & 7), ep0 + 4 * l + 4, stage[q.lane]);
         }
       }
       // ================= P4: FFN2 columns [16 member, +16) over K = 2048 (each wave chains its 4 chunks of 128, 4 partials) -> y2
@@ -1146,7 +1131,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         set_quad(q, qd);
         const int R = q.R;
         q.hop = hop_slot(q, s, l);
-        q.prof_on = q.prof != nullptr && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
+        q.prof_on = PROF && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
         const f4 p_bias = *(const f4*)(lp + FP_B2 + 16 * q.member + 4 * (q.lane >> 4));
         MG_STAMP(q, 19);
         MG_BAR();                                                          // B1: HS holds the FFN hidden
@@ -1594,31 +1579,20 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
         set_quad(q, qd);
         const int R = q.R;
         q.hop = hop_slot(q, s, l);
-        const f4 p_bias = *(const f4*)(lp + FP_B1 + 64 * q.member + 32 * (q.cw & 1) + 4 * (q.lane >> 4));
-        const f4 p_bias2 = *(const f4*)(lp + FP_B1 + 64 * q.member + 32 * (q.cw & 1) + 16 + 4 * (q.lane >> 4));
-        gemm_chunk<4>(q, wC, (const _Float16*)(smem + L_XS) + (qd & 1) * RMAX * XS_LD, XS_LD, q.cw, q.cw * 4);
-        compute_barrier(q, cgen);
-        if (*st_abort(q)) return;
-        if (q.cw < 2) {
-          const f4* red = (const f4*)(smem + L_RED);
+        const f4 p_bias = *(const f4*)(lp + FP_B1 + 64 * q.member + 16 * q.cw + 4 * (q.lane >> 4));
+        f4 v = gemm_tile_k512(q, wC, (const _Float16*)(smem + L_XS) + (qd & 1) * RMAX * XS_LD, XS_LD);
+        {
+          // tile cw of the member's four, published by the wave that computed it (see compute_role)
           const int r = q.lane & 15;
-          unsigned* stage = (unsigned*)(smem + L_STAGE) + q.cw * 256;
+          unsigned* stage = (unsigned*)(smem + L_STAGE) + q.cw * 64;
+          v += p_bias;
           if (r < R) {
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-              const int tile = 2 * q.cw + tt;
-              const f4 v0 = red[red_idx(0 * 4 + tile, q.lane)], v1 = red[red_idx(1 * 4 + tile, q.lane)],
-                       v2 = red[red_idx(2 * 4 + tile, q.lane)], v3 = red[red_idx(3 * 4 + tile, q.lane)];
-              f4 v = v0;
-              v += v1; v += v2; v += v3;
-              v += tt == 0 ? p_bias : p_bias2;
-              const int w0 = r * 16 + tt * 8 + 2 * (q.lane >> 4);
-              stage[w0] = pack_h2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
-              stage[w0 + 1] = pack_h2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-            }
+            const int w0 = r * 8 + 2 * (q.lane >> 4);
+            stage[w0] = pack_h2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+            stage[w0 + 1] = pack_h2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
           }
-          if (q.lane < R * 16)
-            gstore(q.hop + HOP_D + (q.lane >> 4) * 1024 + 32 * q.member + 16 * q.cw + (q.lane & 15), ep0 + 4 * l + 4, stage[q.lane]);
+          if (q.lane < R * 8)
+            gstore(q.hop + HOP_D + (q.lane >> 3) * 1024 + 32 * q.member + 8 * q.cw + (q.lane & 7), ep0 + 4 * l + 4, stage[q.lane]);
         }
       }
       // ================= P4: FFN2
@@ -1719,7 +1693,9 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
 
 // MODE 0: one quad per group (B <= 32); 1: several quads, one after the other in every phase (kept for A/B: GSV_MEGA_QUADS=seq);
 // 2: several quads, pipelined (default for 32 < B <= 128)
-template <int MODE>
+// PROF: the in-kernel stamps (tools/mega_prof.py) are compiled in only for measurement launches -- as run-time tests they
+// cost ~100 scalar instructions per layer and wave
+template <int MODE, bool PROF>
 __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Ctx c;
@@ -1759,16 +1735,12 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
   set_quad(c, 0);
   c.hop_base = (gu64*)a.hop + (size_t)c.group * HOP_GROUP_ALL;
   c.hop = c.hop_base;
-  c.ring = a.ring > 0 ? a.ring : 1;
-  c.nlayer = a.L + 1;
-  c.bulk_plain = c.ring > 1 && ((a.hint_mask >> 5) & 1);
   c.err = (gu32*)a.err;
   c.prof = a.prof ? a.prof + ((size_t)blockIdx.x * 8 + c.wave) * 32 : nullptr;
   c.prof_on = false;
   c.hint_miss16 = (a.hint_mask >> 8) & 31;
   c.hint_pipe = (a.hint_mask >> 4) & 1;
-  c.hint_stride = 1 << ((a.hint_mask >> 13) & 7);
-  c.hint_one = (a.hint_mask >> 6) & 1;
+  c.hint_spread = (a.hint_mask >> 7) & 1;
   const int lane = c.lane, Rtot = c.Rtot;
   const StepParams sp = *a.sp;
 
@@ -1801,8 +1773,8 @@ __global__ __launch_bounds__(MG_THREADS, 1) void t2s_mega_kernel(MegaArgs a) {
     if (c.comm) comm_role_pipe(a, c, sp);
     else compute_role_pipe(a, c);
   } else {
-    if (c.comm) comm_role<MODE == 1>(a, c, sp);
-    else compute_role<MODE == 1>(a, c);
+    if (c.comm) comm_role<MODE == 1, PROF>(a, c, sp);
+    else compute_role<MODE == 1, PROF>(a, c);
   }
 }
 
@@ -1850,9 +1822,10 @@ void mega_pack_layer(const float* qkv_w, const float* out_w, const float* w1, co
     for (int w = 0; w < 4; ++w) {
       _Float16* base = pm + ((size_t)j * 4 + w) * per * 512;
       for (int ks = 0; ks < 4; ++ks) pack_frag(out_w, D, 16 * j, D, 128 * w + 32 * ks, base + (size_t)ks * 512);
-      for (int t = 0; t < 4; ++t)
+      // FFN1: wave w owns tile w (columns 64 j + 16 w, +16) over the whole K: slot 4 c + ks = K chunk c, k-step ks
+      for (int c = 0; c < 4; ++c)
         for (int ks = 0; ks < 4; ++ks)
-          pack_frag(w1, D, 64 * j + 16 * t, FF, 128 * w + 32 * ks, base + (size_t)(WI_P2 + t * 4 + ks) * 512);
+          pack_frag(w1, D, 64 * j + 16 * w, FF, 128 * c + 32 * ks, base + (size_t)(WI_P2 + c * 4 + ks) * 512);
       for (int cc = 0; cc < 4; ++cc)
         for (int ks = 0; ks < 4; ++ks)
           pack_frag(w2, FF, 16 * j, D, 128 * (4 * w + cc) + 32 * ks, base + (size_t)(WI_P2 + WI_P3 + cc * 4 + ks) * 512);
@@ -1883,16 +1856,20 @@ int launch_t2s_mega(const MegaArgs& a, hipStream_t s) {
   // every launch: the attribute belongs to the (function, device) pair, and TTS.set_device may have moved the handle's owner
   // to another GPU of the process since the last launch (mega_census does the same)
   static const bool seq_quads = getenv("GSV_MEGA_QUADS") && !strcmp(getenv("GSV_MEGA_QUADS"), "seq");
+#define GSV_MEGA_LAUNCH(MODE, PROF)                                                                                              \
+  do {                                                                                                                          \
+    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel<MODE, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL)); \
+    hipLaunchKernelGGL((t2s_mega_kernel<MODE, PROF>), dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);                            \
+  } while (0)
+  const bool prof = a.prof != nullptr;                // measurement launches (tools/mega_prof.py): stamps compiled in
   if (a.B > RMAX * MG_GROUPS && seq_quads) {          // more than one quad per group, one after the other (A/B)
-    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
-    hipLaunchKernelGGL(t2s_mega_kernel<1>, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
-  } else if (a.B > RMAX * MG_GROUPS) {                // pipelined quads
-    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
-    hipLaunchKernelGGL(t2s_mega_kernel<2>, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
+    if (prof) GSV_MEGA_LAUNCH(1, true); else GSV_MEGA_LAUNCH(1, false);
+  } else if (a.B > RMAX * MG_GROUPS) {                // pipelined quads (no stamps)
+    GSV_MEGA_LAUNCH(2, false);
   } else {
-    GSV_HIP(hipFuncSetAttribute((const void*)t2s_mega_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
-    hipLaunchKernelGGL(t2s_mega_kernel<0>, dim3(MG_NWG), dim3(MG_THREADS), L_TOTAL, s, a);
+    if (prof) GSV_MEGA_LAUNCH(0, true); else GSV_MEGA_LAUNCH(0, false);
   }
+#undef GSV_MEGA_LAUNCH
   GSV_HIP(hipGetLastError());
   return GSV_OK;
 }
