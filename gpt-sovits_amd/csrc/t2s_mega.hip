@@ -52,6 +52,12 @@ typedef unsigned long long u64;
 // stream adding up instead of overlapping with it.  LDS traffic of this wave is complete (lgkmcnt(0)) before the barrier;
 // the "memory" clobber keeps the compiler from moving memory operations across it.
 #define MG_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// The (sticky) abort flag is tested ONCE per layer: read at the top of the layer, acted on behind the layer's first barrier.
+// Round 2 tested it behind every barrier -- 14 LDS round trips of ~100 cycles per layer on the critical path; read right in
+// front of the barrier instead, the round trip delays the barrier arrival (measured: -1 % at 32 rows, +1.7 % at 128).  A wave
+// that has failed has set the error word and returned (a finished wave no longer counts at s_barrier); its workgroup follows
+// within a layer, the other workgroups through their bounded hop waits, and the launch is re-run from the snapshot.
+#define MG_BAR_AL(q) do { MG_BAR(); if (ab_l) return; } while (0)
 
 namespace {
 
@@ -181,22 +187,28 @@ __device__ __forceinline__ lds_int* st_cbar(const Ctx&) { return (lds_int*)(unsi
 // layer's K/V loads during P1): an arrival counter in LDS; LDS operations of a wave complete in order, so the add is behind
 // the wave's earlier LDS writes.  `gen` counts arrivals expected so far (same in every compute wave).
 __device__ __noinline__ void mega_fail(gu32* err, int lane, unsigned epoch, unsigned code);
-__device__ __forceinline__ void compute_barrier(const Ctx& q, int& gen) {
+__device__ __forceinline__ bool compute_barrier(const Ctx& q, int& gen) {
   gen += 4;
   if (q.lane == 0) __hip_atomic_fetch_add(st_cbar(q), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   unsigned spins = 0;
-  while (*(lds_vint*)st_cbar(q) < gen && !*st_abort(q) && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(0);
+  int ab = *st_abort(q);           // returned to the caller: read in front of the spin, not behind it
+  while (*(lds_vint*)st_cbar(q) < gen && !(ab = *st_abort(q)) && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(0);
   // a wave that gives up must not go on to reduce partial sums another wave has not written: like every other bounded spin
   // of the engine it sets the abort flag and the error word (code 0x40), and the caller returns at its abort test
-  if (spins >= (1u << 24)) mega_fail(q.err, q.lane, (unsigned)gen, 0x40u);
+  if (spins >= (1u << 24)) { mega_fail(q.err, q.lane, (unsigned)gen, 0x40u); ab = 1; }
   asm volatile("" ::: "memory");
+  return ab != 0;
 }
 
 // by value: a `const Ctx&` parameter of a non-inlined function forces the whole Ctx into scratch memory, re-stored at the
 // start of every phase (30 scratch instructions in the hot loops, seen in the ISA)
 __device__ __noinline__ void mega_fail(gu32* err, int lane, unsigned epoch, unsigned code) {
-  *(lds_vint*)((lds_vint*)(unsigned)L_ST + 3 * ST_N) = 1;               // st_abort
-  if (lane == 0) {
+  lds_vint* ab = (lds_vint*)(unsigned)L_ST + 3 * ST_N;                  // st_abort
+  const int was = *ab;
+  *ab = 1;
+  // the FIRST failure of a workgroup is the one reported: its waves run on to the end of the layer (abort is tested once per
+  // layer), and every bounded wait they still meet gives up at once
+  if (lane == 0 && !was) {
     __hip_atomic_store(err + 1, epoch, RLX_AGENT);
     __hip_atomic_store(err + 2, (unsigned)blockIdx.x, RLX_AGENT);
     __hip_atomic_store(err + 3, code, RLX_AGENT);
@@ -759,6 +771,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
   for (int s = 0; s < a.nsteps; ++s) {
     const unsigned ep0 = a.ep_base + (unsigned)s * (unsigned)EPS;  // epoch of hop i of this step = ep0 + i + 1
     for (int l = 0; l < a.L; ++l) {
+      const int ab_l = *st_abort(q);       // the abort test of this layer: read here, acted on behind the first barrier
       const float* lp = a.fpack + (size_t)l * FP_LAYER;
       // ================= P1 of every quad: hop A -> LayerNorm; the compute waves run QKV, append and attention
       for (int qd = 0; qd < nq; ++qd) {
@@ -800,8 +813,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
           }
         }
         MG_STAMP(q, 1);
-        MG_BAR();                                                          // B1
-        if (*st_abort(q)) return;
+        MG_BAR_AL(q);                                                       // B1
         if (l == 0 && s > 0 && qd == 0 && group_done(q)) return;           // every row of the group has finished
         MG_STAMP(q, 2);
         // K/V of the NEXT slot's quad: the next quad of this layer, else quad 0 of the next layer (across the step boundary the
@@ -841,8 +853,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
           }
         }
         MG_STAMP(q, 6);
-        MG_BAR();                                                          // B1
-        if (*st_abort(q)) return;
+        MG_BAR();                                                           // B1
         MG_STAMP(q, 7);
         MG_BAR();                                                          // B2
         MG_STAMP(q, 8);
@@ -858,8 +869,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
           if (sweep_wide<4>(q, q.hop + HOP_C + ra * 512, ep0 + 4 * l + 3, qc, 4u, a.hint_mask & 4)) ln_row_wide(q, ra, qc, gC, bC);
         }
         MG_STAMP(q, 9);
-        MG_BAR();                                                          // B1
-        if (*st_abort(q)) return;
+        MG_BAR();                                                           // B1
         MG_STAMP(q, 10);
         if (MULTI) MG_BAR();                                               // B2 (sequential quads only: see compute_role)
         MG_STAMP(q, 11);
@@ -879,8 +889,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
           }
         }
         MG_STAMP(q, 12);
-        MG_BAR();                                                          // B1
-        if (*st_abort(q)) return;
+        MG_BAR();                                                           // B1
         MG_STAMP(q, 13);
         MG_BAR();                                                          // B2
         MG_STAMP(q, 14);
@@ -897,8 +906,7 @@ __device__ __forceinline__ void comm_role(const MegaArgs& a, const Ctx& c0, cons
         u4v qa[4];
         if (sweep_wide<4>(q, q.hop + HOP_A + ra * 512, epA, qa, 6u, a.hint_mask & 1)) ln_row_wide(q, ra, qa, gA, bA);   // norm2 of the last layer
       }
-      MG_BAR();                                                            // B1
-      if (*st_abort(q)) return;
+      MG_BAR();                                                             // B1
       MG_BAR();                                                            // B2
     }
     // ---- sampling (see run_sampler)
@@ -950,6 +958,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
   for (int s = 0; s < a.nsteps; ++s) {
     const unsigned ep0 = a.ep_base + (unsigned)s * (unsigned)EPS;
     for (int l = 0; l < a.L; ++l) {
+      const int ab_l = *st_abort(q);       // the abort test of this layer: read here, acted on behind the first barrier
       const float* lp = a.fpack + (size_t)l * FP_LAYER;
       // ================= P1: q,k,v of head `head` for the own rows, attention (K/V append: see P2)
       // (the next phase's weight slice is requested in EVERY quad's slot, not only the first: a request under a run-time
@@ -968,8 +977,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         const int rj_which = (q.lane >> 3) % 3, rj_e = 4 * (q.lane & 7);
         const f4 p1_bias = q.lane < 24 ? *(const f4*)(lp + FP_QKVB + rj_which * D + q.head * HD + rj_e) : (f4){0.f, 0.f, 0.f, 0.f};
         MG_STAMP(q, 1);
-        MG_BAR();                                                          // B1: XS / XRES hold LN(y)
-        if (*st_abort(q)) return;
+        MG_BAR_AL(q);                                                       // B1: XS / XRES hold LN(y)
         if (first && l == 0 && s > 0 && group_done(q)) return;
         MG_STAMP(q, 2);
         wload(wB, pm_src(l, 0));                                           // every quad's slot (see the note above the loop)
@@ -978,8 +986,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         if (MULTI && q.cw == 0 && (q.lane & 15) < R)                       // the out-projection's residual operand of this quad
           *rs_slot(0, qd) = *(const f4*)((const float*)(smem + L_XRES) + (q.lane & 15) * D + 16 * q.member + 4 * (q.lane >> 4));
         MG_STAMP(q, 3);
-        compute_barrier(q, cgen);                                          // B2 (compute waves only)
-        if (*st_abort(q)) return;
+        if (compute_barrier(q, cgen)) return;                              // B2 (compute waves only)
         MG_STAMP(q, 4);
         {
           // split-K reduce of q, k, v (+ bias) by the wave that consumes them: each attention wave sums the 96 values of ITS row
@@ -1009,8 +1016,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         // the partials of a row's two waves meet through LDS.  This barrier is B4 itself (the attention has released the K/V
         // image): the comm waves only have to ISSUE the next layer's K/V loads before it, which takes ~1.5 us since the row
         // state is read once per call (it was 3.5 us, and a compute-only barrier stood here so that the publish did not wait)
-        MG_BAR();                                                          // B4
-        if (*st_abort(q)) return;
+        MG_BAR();                                                           // B4
         MG_STAMP(q, 9);
         if (q.cw == 0) {
           // combine the 2 waves of each own row; lane = ro * 32 + e
@@ -1052,8 +1058,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         q.prof_on = PROF && s == a.prof_step && l == a.prof_layer && first;
         const f4 p_bias = *(const f4*)(lp + FP_OUTB + 16 * q.member + 4 * (q.lane >> 4));
         MG_STAMP(q, 11);
-        MG_BAR();                                                          // B1: AT holds the attention output
-        if (*st_abort(q)) return;
+        MG_BAR();                                                           // B1: AT holds the attention output
         MG_STAMP(q, 12);
         wload(wC, pm_src(l, WI_P2));
         gemm_chunk<1>(q, wB, (const _Float16*)(smem + L_AT), XS_LD, q.cw, q.cw);
@@ -1098,8 +1103,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         q.prof_on = PROF && s == a.prof_step && l == a.prof_layer && first;
         const f4 p_bias = *(const f4*)(lp + FP_B1 + 64 * q.member + 16 * q.cw + 4 * (q.lane >> 4));       // tile cw of the member's four
         MG_STAMP(q, 15);
-        MG_BAR();                                                          // B1: XS / XRES hold LN1(y1)
-        if (*st_abort(q)) return;
+        MG_BAR();                                                           // B1: XS / XRES hold LN1(y1)
         MG_STAMP(q, 16);
         wload(wD, pm_src(l, WI_P2 + WI_P3));
         f4 v = gemm_tile_k512(q, wC, (const _Float16*)(smem + L_XS), XS_LD);
@@ -1134,8 +1138,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
         q.prof_on = PROF && s == a.prof_step && l == a.prof_layer && qd == a.prof_quad;
         const f4 p_bias = *(const f4*)(lp + FP_B2 + 16 * q.member + 4 * (q.lane >> 4));
         MG_STAMP(q, 19);
-        MG_BAR();                                                          // B1: HS holds the FFN hidden
-        if (*st_abort(q)) return;
+        MG_BAR();                                                           // B1: HS holds the FFN hidden
         MG_STAMP(q, 20);
         if (l + 1 < a.L) wload(wA0, p1_src(l + 1));                        // P1 has finished with wA0 for every quad
         else wload(wA0, a.lpack + (((size_t)q.member * 4 + q.cw) * WI_LG * 512) / 8 + q.lane);
@@ -1204,8 +1207,7 @@ __device__ __forceinline__ void compute_role(const MegaArgs& a, const Ctx& c0) {
       const int R = q.R;
       q.hop = hop_slot(q, s, a.L);
       q.prof_on = false;
-      MG_BAR();                                                            // B1: XS holds LN2(y) of the last layer
-      if (*st_abort(q)) return;
+      MG_BAR();                                                             // B1: XS holds LN2(y) of the last layer
       gemm_chunk<3>(q, wA0, (const _Float16*)(smem + L_XS), XS_LD, q.cw, q.cw * 3);
       if (!MULTI) wload(wA0, p1_src(0));                                   // next step's layer 0 (two hops away; wA1 is there already)
       MG_BAR();                                                            // B2
@@ -1288,6 +1290,7 @@ __device__ __forceinline__ void comm_role_pipe(const MegaArgs& a, const Ctx& c0,
   for (int s = 0; s < a.nsteps; ++s) {
     const unsigned ep0 = a.ep_base + (unsigned)s * (unsigned)EPS;
     for (int l = 0; l < a.L; ++l) {
+      const int ab_l = *st_abort(q);       // the abort test of this layer: read here, acted on behind the first barrier
       const float* lp = a.fpack + (size_t)l * FP_LAYER;
       // hop A of quad qd -> LayerNorm -> XS copy qd & 1 (+ the residual columns of the out-projection)
       auto sweep_a = [&](int qd) {
@@ -1324,16 +1327,14 @@ __device__ __forceinline__ void comm_role_pipe(const MegaArgs& a, const Ctx& c0,
         }
       }
       for (int qd = 0; qd < nq; ++qd) {
-        MG_BAR();                                                          // B_a
-        if (*st_abort(q)) return;
+        MG_BAR_AL(q);                                                       // B_a
         if (l == 0 && s > 0 && qd == 0 && group_done(q)) return;
         relaunder(q);
         // the image of THIS slot's quad (requested one slot ago) -> LDS.  At (l = 0, qd = 0) of a step after the first the rows'
         // state has just advanced: the image was requested with extra = 1 at the end of the previous step, the store uses the
         // advanced state with extra = 0 -- the same positions
         kv_stage_store(q, qd, 0, kvs);
-        MG_BAR();                                                          // B_b
-        if (*st_abort(q)) return;
+        MG_BAR();                                                           // B_b
         // the NEXT slot's image (the compute waves run the reduce and the attention meanwhile)
         const bool kv_same = qd + 1 < nq;
         const int kv_nq = kv_same ? qd + 1 : 0;
@@ -1366,7 +1367,6 @@ __device__ __forceinline__ void comm_role_pipe(const MegaArgs& a, const Ctx& c0,
       sweep_b(0);
       for (int qd = 0; qd < nq; ++qd) {
         MG_BAR();
-        if (*st_abort(q)) return;
         if (qd + 1 < nq) sweep_b(qd + 1);
       }
       // ================= P3: hop C -> LayerNorm1 -> XS copies (+ the residual columns of FFN2)
@@ -1382,7 +1382,6 @@ __device__ __forceinline__ void comm_role_pipe(const MegaArgs& a, const Ctx& c0,
       sweep_c(0);                       // no barrier between the phases: this sweep overlaps the last out-projection slot
       for (int qd = 0; qd < nq; ++qd) {
         MG_BAR();
-        if (*st_abort(q)) return;
         if (qd + 1 < nq) sweep_c(qd + 1);
       }
       // ================= P4: hop D -> HS copies
@@ -1402,7 +1401,6 @@ __device__ __forceinline__ void comm_role_pipe(const MegaArgs& a, const Ctx& c0,
       sweep_d(0);
       for (int qd = 0; qd < nq; ++qd) {
         MG_BAR();
-        if (*st_abort(q)) return;
         if (qd + 1 < nq) sweep_d(qd + 1);
       }
     }
@@ -1419,11 +1417,9 @@ __device__ __forceinline__ void comm_role_pipe(const MegaArgs& a, const Ctx& c0,
     sweep_t(0);
     for (int qd = 0; qd < nq; ++qd) {
       MG_BAR();
-      if (*st_abort(q)) return;
       if (qd + 1 < nq) sweep_t(qd + 1);
     }
-    MG_BAR();                // end of the step's GEMMs: the last logits GEMM has read its XS copy (the next step's first sweep rewrites copy 0)
-    if (*st_abort(q)) return;
+    MG_BAR();                 // end of the step's GEMMs: the last logits GEMM has read its XS copy (the next step's first sweep rewrites copy 0)
     if (sampler) MG_RUN_SAMPLER();
   }
 }
@@ -1451,21 +1447,20 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
   for (int s = 0; s < a.nsteps; ++s) {
     const unsigned ep0 = a.ep_base + (unsigned)s * (unsigned)EPS;
     for (int l = 0; l < a.L; ++l) {
+      const int ab_l = *st_abort(q);       // the abort test of this layer: read here, acted on behind the first barrier
       const float* lp = a.fpack + (size_t)l * FP_LAYER;
       // ================= P1.  The first slot's barrier and the next phase's weight request stand in FRONT of the quad loop: a
       // request inside the loop is either conditional (`if (qd == 0)`: a conditional definition keeps the register array's old
       // contents alive around the whole loop, ~100 spilled VGPRs) or repeated per quad -- and the weight loads are
       // non-temporal, so the repeats miss L2 and every quad streamed the layer's slice again from the memory side: 6 GB per
       // step at B = 128, no faster than the sequential quads (1.07 ms per step both)
-      MG_BAR();                                                            // B_a of quad 0
-      if (*st_abort(q)) return;
+      MG_BAR_AL(q);                                                         // B_a of quad 0
       if (l == 0 && s > 0 && group_done(q)) return;
       relaunder(q);
       wload(wB, pm_src(l, 0));
       for (int qd = 0; qd < nq; ++qd) {
         if (qd > 0) {
-          MG_BAR();                                                        // B_a: XS copy qd & 1 holds LN(y); the image is free
-          if (*st_abort(q)) return;
+          MG_BAR();                                                         // B_a: XS copy qd & 1 holds LN(y); the image is free
         }
         relaunder(q);
         set_quad(q, qd);
@@ -1477,8 +1472,7 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
         const _Float16* xs = (const _Float16*)(smem + L_XS) + (qd & 1) * RMAX * XS_LD;
         gemm_chunk<3>(q, wA0, xs, XS_LD, q.cw, q.cw * 6);
         gemm_chunk<3>(q, wA1, xs, XS_LD, q.cw, q.cw * 6 + 3);
-        MG_BAR();                                                          // B_b: partials parked, this quad's K/V image stored
-        if (*st_abort(q)) return;
+        MG_BAR();                                                           // B_b: partials parked, this quad's K/V image stored
         {
           const f4* red = (const f4*)(smem + L_RED);
           _Float16* qkv_s = (_Float16*)(smem + L_QKV);
@@ -1495,8 +1489,7 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
           asm volatile("" ::: "memory");
         }
         attention_part<2>(a, q, l, q.cw);
-        compute_barrier(q, cgen);                                          // the partials of a row's two waves meet (compute waves only)
-        if (*st_abort(q)) return;
+        if (compute_barrier(q, cgen)) return;                                          // the partials of a row's two waves meet (compute waves only)
         if (q.cw == 0) {
           const float* s_m = (const float*)(smem + L_ATT);
           const float* s_acc = s_m + 8;
@@ -1531,14 +1524,12 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
         }
       }
       // ================= P2: out-projection
-      MG_BAR();                                                            // AT copy 0 holds quad 0's attention output
-      if (*st_abort(q)) return;
+      MG_BAR();                                                             // AT copy 0 holds quad 0's attention output
       relaunder(q);
       wload(wC, pm_src(l, WI_P2));
       for (int qd = 0; qd < nq; ++qd) {
         if (qd > 0) {
-          MG_BAR();                                                        // AT copy qd & 1 holds the attention output
-          if (*st_abort(q)) return;
+          MG_BAR();                                                         // AT copy qd & 1 holds the attention output
         }
         relaunder(q);
         set_quad(q, qd);
@@ -1546,8 +1537,7 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
         q.hop = hop_slot(q, s, l);
         const f4 p_bias = *(const f4*)(lp + FP_OUTB + 16 * q.member + 4 * (q.lane >> 4));
         gemm_chunk<1>(q, wB, (const _Float16*)(smem + L_AT) + (qd & 1) * RMAX * XS_LD, XS_LD, q.cw, q.cw);
-        compute_barrier(q, cgen);
-        if (*st_abort(q)) return;
+        if (compute_barrier(q, cgen)) return;
         if (q.cw == 0) {
           const f4* red = (const f4*)(smem + L_RED);
           const int r = q.lane & 15;
@@ -1566,14 +1556,12 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
         }
       }
       // ================= P3: FFN1 + ReLU
-      MG_BAR();                                                            // XS copy 0 holds LN1(y1) of quad 0
-      if (*st_abort(q)) return;
+      MG_BAR();                                                             // XS copy 0 holds LN1(y1) of quad 0
       relaunder(q);
       wload(wD, pm_src(l, WI_P2 + WI_P3));
       for (int qd = 0; qd < nq; ++qd) {
         if (qd > 0) {
-          MG_BAR();                                                        // XS copy qd & 1 holds LN1(y1)
-          if (*st_abort(q)) return;
+          MG_BAR();                                                         // XS copy qd & 1 holds LN1(y1)
         }
         relaunder(q);
         set_quad(q, qd);
@@ -1596,16 +1584,14 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
         }
       }
       // ================= P4: FFN2
-      MG_BAR();                                                            // HS copy 0 holds quad 0's FFN hidden
-      if (*st_abort(q)) return;
+      MG_BAR();                                                             // HS copy 0 holds quad 0's FFN hidden
       relaunder(q);
       if (l + 1 < a.L) wload(wA0, p1_src(l + 1));                          // P1 has finished with both halves for every quad
       else wload(wA0, a.lpack + (((size_t)q.member * 4 + q.cw) * WI_LG * 512) / 8 + q.lane);
       wload(wA1, p1_src(l + 1 < a.L ? l + 1 : 0) + (size_t)(WI_P1 / 2) * 64);
       for (int qd = 0; qd < nq; ++qd) {
         if (qd > 0) {
-          MG_BAR();                                                        // HS copy qd & 1 holds the FFN hidden
-          if (*st_abort(q)) return;
+          MG_BAR();                                                         // HS copy qd & 1 holds the FFN hidden
         }
         relaunder(q);
         set_quad(q, qd);
@@ -1639,8 +1625,7 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
           }
           if (rowl < RMAX) red[red_idx(q.cw, q.lane)] = acc;
         }
-        compute_barrier(q, cgen);
-        if (*st_abort(q)) return;
+        if (compute_barrier(q, cgen)) return;
         if (q.cw == 0) {
           const f4* red = (const f4*)(smem + L_RED);
           const int r = q.lane & 15;
@@ -1666,11 +1651,9 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
       set_quad(q, qd);
       const int R = q.R;
       q.hop = hop_slot(q, s, a.L);
-      MG_BAR();                                                            // XS copy qd & 1 holds LN2(y) of the last layer
-      if (*st_abort(q)) return;
+      MG_BAR();                                                             // XS copy qd & 1 holds LN2(y) of the last layer
       gemm_chunk<3>(q, wA0, (const _Float16*)(smem + L_XS) + (qd & 1) * RMAX * XS_LD, XS_LD, q.cw, q.cw * 3);
-      compute_barrier(q, cgen);
-      if (*st_abort(q)) return;
+      if (compute_barrier(q, cgen)) return;
       if (q.cw < 3) {
         const f4* red = (const f4*)(smem + L_RED);
         const int t = q.cw, r = q.lane & 15;
@@ -1685,8 +1668,7 @@ __device__ __forceinline__ void compute_role_pipe(const MegaArgs& a, const Ctx& 
           gstore(q.hop + HOP_E + (q.lane >> 4) * VPAD + 16 * tile + (q.lane & 15), epE, __float_as_uint(stage[q.lane]));
       }
     }
-    MG_BAR();                                                              // end of the step's GEMMs
-    if (*st_abort(q)) return;
+    MG_BAR();                                                               // end of the step's GEMMs
     wload(wA0, p1_src(0));                                                 // the next step's first slice follows the logits slice's last reader
   }
 }
