@@ -334,6 +334,13 @@ template <int NLINES>
 __device__ __forceinline__ int hint_line(const Ctx& c) {
   return ((c.member + 16) & 31) * NLINES / 32 + (NLINES >= 64 ? 1 : 0);
 }
+// pauses (s_sleep units of 64 clocks) between hint polls and between full passes of sweep_wide (compile-time: A/B by library)
+#ifndef GSV_HINT_SLEEP
+#define GSV_HINT_SLEEP 1
+#endif
+#ifndef GSV_PASS_SLEEP
+#define GSV_PASS_SLEEP 2
+#endif
 // one wave, one row of NQ * 128 granules
 template <int NQ>
 __device__ __forceinline__ bool sweep_wide(const Ctx& c, gu64* g, unsigned epoch, u4v (&q)[NQ], unsigned code, bool hint) {
@@ -349,7 +356,7 @@ __device__ __forceinline__ bool sweep_wide(const Ctx& c, gu64* g, unsigned epoch
         mega_fail(c.err, c.lane, epoch, code | 0x100u);
         return false;
       }
-      if (spins < 8) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
+      if (spins < 8) __builtin_amdgcn_s_sleep(GSV_HINT_SLEEP); else __builtin_amdgcn_s_sleep(4);
     }
   }
   const gu64* p0 = g + 2 * c.lane;
@@ -363,7 +370,7 @@ __device__ __forceinline__ bool sweep_wide(const Ctx& c, gu64* g, unsigned epoch
       mega_fail(c.err, c.lane, epoch, code);
       return false;
     }
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(GSV_PASS_SLEEP);
   }
 }
 
