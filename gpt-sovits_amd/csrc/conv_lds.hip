@@ -420,18 +420,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_lds_kernel(ConvArgs a) {
       *(F*)(ws + ((size_t)buf * CT + row) * LDX + col * G) = wr[i];
     }
   };
-  {
-    F xr[NLD], wr[NLD];
-    load_tiles(0, xr, wr);
-    store_tiles(0, xr, wr);
-  }
-  __syncthreads();
+  // Two chunks in flight (round 3, the 8-wave variant = ONE workgroup per CU): chunk c is multiplied from LDS buffer c & 1 while chunk c + 1 waits in one register set and
+  // chunk c + 2 is being requested into the other.  With ONE chunk of prefetch distance an iteration (16-32 MFMAs per wave,
+  // ~0.2 us) could not be shorter than a global-load round trip (1-2 us under load): the K = 512 GEMMs of the AR prefill ran 8
+  // such iterations per tile, 9 x their MFMA time.  The loop is unrolled by two so that the register sets keep static names.
   const int nchunks = (K + BK - 1) / BK;
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    F xr[NLD], wr[NLD];
-    const bool more = c + 1 < nchunks;
-    if (more) load_tiles((c + 1) * BK, xr, wr);
+  auto compute = [&](int buf) {
     const T* xb = xs + (size_t)buf * TT * LDX;
     const T* wb = ws + (size_t)buf * CT * LDX;
 #pragma unroll
@@ -447,9 +441,45 @@ __global__ __launch_bounds__(NW * 64) void gemm_lds_kernel(ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < TN; ++n) mma32l(acc[m][n], af[m], bf[n]);
     }
-    if (more) {
-      store_tiles(buf ^ 1, xr, wr);
+  };
+  if constexpr (NW == 8) {
+    F xa[NLD], wa[NLD], xq[NLD], wq[NLD];
+    load_tiles(0, xa, wa);
+    store_tiles(0, xa, wa);
+    load_tiles(BK, xa, wa);                            // chunk 1 (zeros beyond K: load_tiles tests every element)
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+      load_tiles((c + 2) * BK, xq, wq);
+      compute(0);
+      if (c + 1 >= nchunks) break;
+      store_tiles(1, xa, wa);
       __syncthreads();
+      load_tiles((c + 3) * BK, xa, wa);
+      compute(1);
+      if (c + 2 < nchunks) {
+        store_tiles(0, xq, wq);
+        __syncthreads();
+      }
+    }
+  } else {
+    // 4 waves: two workgroups per CU already keep two chunks in flight per CU, and the second register set would cost the second
+    // workgroup (118 -> 214 VGPRs + 64 accumulators); measured: 39.3 vs 40.1 us on the prefill's QKV / FFN1 launches
+    {
+      F xr[NLD], wr[NLD];
+      load_tiles(0, xr, wr);
+      store_tiles(0, xr, wr);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+      const int buf = c & 1;
+      F xr[NLD], wr[NLD];
+      const bool more = c + 1 < nchunks;
+      if (more) load_tiles((c + 1) * BK, xr, wr);
+      compute(buf);
+      if (more) {
+        store_tiles(buf ^ 1, xr, wr);
+        __syncthreads();
+      }
     }
   }
 
@@ -567,7 +597,8 @@ template <typename T> static int try_launch_gemm(const ConvArgs& a, hipStream_t 
   // 8 waves per workgroup where the grid has fewer tiles than the chip has CUs (prefill out-projection / FFN2: 180 tiles, the
   // DiT's QKV: 192, enc_p 1 x 1 convs): the workgroup is alone on its CU; GSV_GEMM_WAVES=4 restores round 2's geometry
   static const int gemm_waves = getenv("GSV_GEMM_WAVES") ? atoi(getenv("GSV_GEMM_WAVES")) : 8;
-  const bool w8 = sizeof(T) == 2 && gemm_waves == 8 && (long long)grid.x * grid.y * grid.z <= 256;
+  static const long long w8_max_tiles = getenv("GSV_GEMM_W8_MAX_TILES") ? atoll(getenv("GSV_GEMM_W8_MAX_TILES")) : 256;   // A/B
+  const bool w8 = sizeof(T) == 2 && gemm_waves == 8 && (long long)grid.x * grid.y * grid.z <= w8_max_tiles;
 #define GSV_GEMM_LAUNCH(R, NTW, W)                                                                                         \
   do {                                                                                                                     \
     auto kern = gemm_lds_kernel<T, R, NTW, W>;                                                                             \
