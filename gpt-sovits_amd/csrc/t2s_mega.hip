@@ -330,9 +330,13 @@ template <> __device__ __forceinline__ void wide_loads<8>(const gu64* p0, u4v (&
 // member's line, and a different one for every member of the group.  With every member polling the same line (round 2: the
 // last line of the row) 32 workgroups re-read one address while its publisher was trying to write it: 297 -> 288 us per step
 // when the polls are spread; two or four lines per member, polls in flight, slower paces all lose (profiles/r03_ab_hint_spread.txt).
+#ifndef GSV_HINT_OFFSET
+#define GSV_HINT_OFFSET 16          // whose line a member polls: member + this.  A publisher on ANOTHER XCD (members 4 x .. 4 x + 3 run
+                                    // on XCD x): +1 / -1 cost 8 %, +4 / +8 / +16 are equal (profiles/r03_ab_hint_spread.txt, 11.)
+#endif
 template <int NLINES>
 __device__ __forceinline__ int hint_line(const Ctx& c) {
-  return ((c.member + 16) & 31) * NLINES / 32 + (NLINES >= 64 ? 1 : 0);
+  return ((c.member + GSV_HINT_OFFSET) & 31) * NLINES / 32 + (NLINES >= 64 ? 1 : 0);
 }
 // pauses (s_sleep units of 64 clocks) between hint polls and between full passes of sweep_wide (compile-time: A/B by library)
 #ifndef GSV_HINT_SLEEP
