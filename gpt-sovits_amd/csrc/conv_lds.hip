@@ -332,11 +332,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_lds_kernel(ConvArgs a, int r
 // ---------------------------------------------------------------------------------------
 // NW = waves per workgroup: 4 (64 x 64 outputs per wave; two workgroups per CU when the grid is large enough) or 8 (64 x 32 per
 // wave: for grids with fewer tiles than CUs, where a workgroup is alone on its CU and a second wave per SIMD hides its stalls)
+#ifndef GSV_GEMM_W8_BK
+#define GSV_GEMM_W8_BK 128
+#endif
 template <typename T, bool RES, bool WNT = false, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void gemm_lds_kernel(ConvArgs a) {
   typedef typename FragL<T>::type F;
   constexpr int G = DT<T>::G, KC = 2 * G;
-  constexpr int BK = 64 * 2 / (int)sizeof(T);        // 64 fp16 / 32 fp32 elements = 128 B per row
+  // K elements per chunk: 128 B per row (64 fp16 / 32 fp32); the 8-wave fp16 form (one workgroup per CU, 139 KB of LDS) stages
+  // 256-B rows: half as many iterations, barriers and load round trips per tile
+  constexpr int BK = (NW == 8 && sizeof(T) == 2 ? GSV_GEMM_W8_BK : 64 * 2 / (int)sizeof(T));
   constexpr int LDX = BK + G;
   constexpr int VPR = BK / G;                        // 8 vectors per row
   constexpr int CT = 128, TT = 128, NT = NW * 64;
@@ -582,7 +587,7 @@ template <typename T> static int try_launch_gemm(const ConvArgs& a, hipStream_t 
   if (a.Z > 1 && ((a.xz % G) || (a.wz % G) || a.res)) return 1;      // batched: head slices must stay 16-byte aligned
   if (a.res && a.res_f32) return 1;
   if (a.ldx % G != 0 || a.ldw % G != 0 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return 1;
-  const size_t lds = (size_t)2 * (128 + 128) * (BK + G) * sizeof(T);     // 73.7 KB; epilogue tile 33.8 KB fits inside
+  size_t lds = (size_t)2 * (128 + 128) * (BK + G) * sizeof(T);           // 73.7 KB; epilogue tile 33.8 KB fits inside
   dim3 grid(cdiv(a.T_virt, 128), cdiv(a.Cout, 128), a.Z);
   static const bool xcd = !(getenv("GSV_GEMM_XCD") && getenv("GSV_GEMM_XCD")[0] == '0');     // A/B switch
   ConvArgs b = a;
@@ -598,7 +603,8 @@ template <typename T> static int try_launch_gemm(const ConvArgs& a, hipStream_t 
   // DiT's QKV: 192, enc_p 1 x 1 convs): the workgroup is alone on its CU; GSV_GEMM_WAVES=4 restores round 2's geometry
   static const int gemm_waves = getenv("GSV_GEMM_WAVES") ? atoi(getenv("GSV_GEMM_WAVES")) : 8;
   static const long long w8_max_tiles = getenv("GSV_GEMM_W8_MAX_TILES") ? atoll(getenv("GSV_GEMM_W8_MAX_TILES")) : 256;   // A/B
-  const bool w8 = sizeof(T) == 2 && gemm_waves == 8 && (long long)grid.x * grid.y * grid.z <= w8_max_tiles;
+  const bool w8 = sizeof(T) == 2 && gemm_waves == 8 && (long long)grid.x * grid.y * grid.z <= w8_max_tiles && a.Cin >= GSV_GEMM_W8_BK;
+  if (w8) lds = (size_t)2 * (128 + 128) * (GSV_GEMM_W8_BK + G) * sizeof(T);       // 139 KB at 128-wide chunks
 #define GSV_GEMM_LAUNCH(R, NTW, W)                                                                                         \
   do {                                                                                                                     \
     auto kern = gemm_lds_kernel<T, R, NTW, W>;                                                                             \
