@@ -110,6 +110,30 @@ def unpack_segments(wire: torch.Tensor, bert: Optional[torch.Tensor] = None) -> 
     return out
 
 
+def join_fragments(frags: List[np.ndarray]) -> np.ndarray:
+    """int16 fragments in submission order -> one array.  When the fragments already lie back to back in ONE host buffer
+    (a job of one batch whose order was not permuted: BASELINE configs[1]) the result is a view of that buffer; otherwise a
+    concatenation.  The copy it saves is 8 MB per batch of 32 x 4 s, ~1 ms of host time per step."""
+    if not frags:
+        return np.zeros(0, dtype=np.int16)
+    frags = [f for f in frags if f.size] or frags[:1]         # empty fragments add nothing (and carry no address)
+    base = frags[0].base
+    if isinstance(base, np.ndarray) and base.ndim == 1 and base.dtype == np.int16 and base.flags.c_contiguous:
+        addr = base.__array_interface__["data"][0]
+        start = frags[0].__array_interface__["data"][0]
+        nxt, ok = start, True
+        for f in frags:
+            if f.base is not base or f.ndim != 1 or f.dtype != np.int16 or (f.size > 1 and f.strides[0] != 2) \
+                    or f.__array_interface__["data"][0] != nxt:
+                ok = False
+                break
+            nxt += 2 * f.size
+        if ok and (start - addr) % 2 == 0:
+            o = (start - addr) // 2
+            return base[o:o + (nxt - start) // 2]
+    return np.concatenate(frags)
+
+
 class ShardedSynthesizer:
     """`synth(segments) -> (int16 1-D numpy array or device tensor, per-fragment sample counts in the order of `segments`)`
     is the local engine call (the TTS wrapper in production, a stub in the gloo tests)."""
@@ -311,7 +335,7 @@ class ShardedSynthesizer:
                 for i, f in zip(idxs, frags):
                     out[i] = f
             keep = [f for f in out if f is not None]
-            return np.concatenate(keep) if keep else np.zeros(0, dtype=np.int16)
+            return join_fragments(keep)
         dev = self.device
         self._job += 1
         job = self._job
@@ -385,4 +409,4 @@ class ShardedSynthesizer:
                 raise exc
             raise RuntimeError(f"sharded synthesis failed on {', '.join(failed)}")
         keep = [f for f in out if f is not None]
-        return np.concatenate(keep) if keep else np.zeros(0, dtype=np.int16)
+        return join_fragments(keep)

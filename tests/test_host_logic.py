@@ -122,6 +122,30 @@ def _stub_synth(segments):
     return (torch.cat(frags) if frags else torch.zeros(0, dtype=torch.int16)), [int(f.numel()) for f in frags]
 
 
+def test_join_fragments_is_a_view_only_when_fragments_are_adjacent_in_order():
+    """the one-batch job of BASELINE configs[1] returns the page-locked result buffer itself; every other layout is copied"""
+    a = np.arange(100, dtype=np.int16)
+    v = sharding.join_fragments([a[0:10], a[10:10], a[10:30]])
+    assert np.shares_memory(v, a) and v.tolist() == list(range(30))
+    for frags in ([a[10:30], a[0:10]], [a[0:10], a[11:30]], [a[0:10], a.copy()[10:30]], [a.copy(), a.copy()], [a[0:10:2]]):
+        v = sharding.join_fragments(frags)
+        assert not np.shares_memory(v, a) and v.tolist() == np.concatenate(frags).tolist()
+    m = np.arange(40, dtype=np.int16).reshape(4, 10)                     # rows of a 2-D buffer: not the 1-D layout, copied
+    assert sharding.join_fragments([m[0], m[1]]).tolist() == list(range(20))
+    assert sharding.join_fragments([]).size == 0 and sharding.join_fragments([a[3:3], a[5:5]]).size == 0
+    bufs = []
+
+    def synth(segs):
+        bufs.append(np.arange(1000 * len(segs), dtype=np.int16))
+        return bufs[-1], [1000] * len(segs)
+    sh = sharding.ShardedSynthesizer(synth, torch.device("cpu"))
+    segs = [_seg(5) for _ in range(8)]
+    out = sh.run(segs)
+    assert np.shares_memory(out, bufs[0]) and out.tolist() == bufs[0].tolist()
+    out = sh.run(segs, batch_size=4)                                     # two batches = two buffers: concatenated
+    assert out.tolist() == bufs[1].tolist() + bufs[2].tolist()
+
+
 def test_sharded_synthesizer_single_process_restores_order():
     segs = [{"phones": [i + 1] * n, "bert_features": torch.zeros(1024, n), "norm_text": "x" * n} for i, n in enumerate((4, 1, 3))]
     sh = sharding.ShardedSynthesizer(_stub_synth, torch.device("cpu"))
