@@ -134,6 +134,33 @@ def join_fragments(frags: List[np.ndarray]) -> np.ndarray:
     return np.concatenate(frags)
 
 
+def place_pieces(pieces, batches: List[List[int]], n_segments: int, dev: torch.device) -> np.ndarray:
+    """`pieces` = (batch index, int16 source tensor, offset of the batch's samples in it, fragment lengths in the batch's
+    order), sources on the host or on `dev`.  Returns the audio of all segments in submission order: ONE buffer (page-locked
+    when `dev` is a GPU), every piece copied once, straight to its place -- a batch of consecutive segments as one copy (D2H
+    for the other ranks' records, host to host for rank 0's own).  Before: one D2H of the whole record + a concatenation of
+    everything (66 MB at N = 8).  A batch nobody delivered leaves its segments empty."""
+    seg_len = [0] * n_segments
+    for k, _src, _o, fl in pieces:
+        for i, ln in zip(batches[k], fl):
+            seg_len[i] = int(ln)
+    offs = np.concatenate([[0], np.cumsum(seg_len, dtype=np.int64)])
+    cuda = dev.type == "cuda"
+    result = torch.empty(int(offs[-1]), dtype=torch.int16, pin_memory=cuda)
+    for k, src, o, fl in pieces:
+        idx = batches[k]
+        if all(idx[j] + 1 == idx[j + 1] for j in range(len(idx) - 1)):
+            n = int(sum(fl))
+            result[int(offs[idx[0]]):int(offs[idx[0]]) + n].copy_(src[o:o + n], non_blocking=True)
+        else:
+            for i, ln in zip(idx, fl):
+                result[int(offs[i]):int(offs[i]) + int(ln)].copy_(src[o:o + int(ln)], non_blocking=True)
+                o += int(ln)
+    if cuda:
+        torch.cuda.current_stream(dev).synchronize()
+    return result.numpy()
+
+
 class ShardedSynthesizer:
     """`synth(segments) -> (int16 1-D numpy array or device tensor, per-fragment sample counts in the order of `segments`)`
     is the local engine call (the TTS wrapper in production, a stub in the gloo tests)."""
@@ -365,17 +392,9 @@ class ShardedSynthesizer:
             dist.send(torch.tensor(table + [0], dtype=torch.int64, device=dev), 0, group=self.group)
             dist.send(pay.view(torch.uint8), 0, group=self.group)
             return None
-        out = [None] * len(segments)
         failed = [f"rank 0: {exc!r}"] if err else []
-        for k, a, fl in mine:
-            self.last_owner[k] = 0
-            host = to_host(a) if a.is_cuda else a.numpy()
-            o = 0
-            for i, ln in zip(batches[k], fl):
-                out[i] = host[o:o + ln]
-                o += ln
-        # every rank's record lands in ONE device buffer (the receives are stream-ordered, nothing waits on the host in
-        # between) and crosses PCIe as one page-locked copy: 7 x 8 MB of int16 at N = 8
+        # sizes and fragment tables of every rank first (the receives are stream-ordered; the payloads follow into ONE device
+        # buffer: 7 x 8 MB of int16 at N = 8), so that every fragment's place in the result is known before a sample moves
         recs = []
         for r in range(1, self.world):
             sizes = torch.zeros(3, dtype=torch.int64, device=dev)
@@ -389,24 +408,27 @@ class ShardedSynthesizer:
         for r, nt, ns, rerr, tab in recs:
             dist.recv(big[o8:o8 + 2 * ns], r, group=self.group)
             o8 += 2 * ns
-        host_all = to_host(big.view(torch.int16)) if recs else np.zeros(0, dtype=np.int16)
+        big16 = big.view(torch.int16)
+        # pieces = (batch, source tensor, offset in it, fragment lengths); a batch nobody delivered leaves its segments empty
+        pieces = []
+        for k, a, fl in mine:
+            self.last_owner[k] = 0
+            pieces.append((k, a.reshape(-1), 0, fl))
         base = 0
         for r, nt, ns, rerr, tab in recs:
             if rerr:
                 failed.append(f"rank {r}")
-            host = host_all[base:base + ns]
-            base += ns
-            t, p, o = tab.tolist(), 0, 0
+            t, p, o = tab.tolist(), 0, base
             while p < nt:
                 k, nf = t[p], t[p + 1]
+                fl = t[p + 2:p + 2 + nf]
                 self.last_owner[k] = r
-                for i, ln in zip(batches[k], t[p + 2:p + 2 + nf]):
-                    out[i] = host[o:o + ln]
-                    o += ln
+                pieces.append((k, big16, o, fl))
+                o += sum(fl)
                 p += 2 + nf
+            base += ns
         if failed:
             if exc is not None:
                 raise exc
             raise RuntimeError(f"sharded synthesis failed on {', '.join(failed)}")
-        keep = [f for f in out if f is not None]
-        return join_fragments(keep)
+        return place_pieces(pieces, batches, len(segments), dev)

@@ -157,3 +157,37 @@ def test_two_pipelines_on_separate_streams_keep_the_engine_correct(pipeline):
     assert len(other_out) >= 1 and all(np.array_equal(a, solo) for a in other_out), "the background pipeline's audio is wrong"
     fb = tts.t2s_model.engine_stats()[1] + other.t2s_model.engine_stats()[1]
     print(f"[engine] two pipelines side by side: {6 + len(other_out)} batches, all equal to the solo result; hand-off fallbacks taken: {fb}")
+
+
+def test_rank0_gather_places_device_and_host_pieces_in_submission_order():
+    """the tail of ShardedSynthesizer.run on rank 0 at N > 1 (sharding.place_pieces), with the sources where they are on a
+    GPU box: the other ranks' records in one device buffer, rank 0's own batch on the host.  8 batches of 32 x 128 000
+    samples (configs[1] at N = 8: 66 MB) + a bucketed batch whose segments are not consecutive + an undelivered batch."""
+    from gsv.sharding import place_pieces
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    nb, per, n = 8, 32, 128000
+    batches = [list(range(k * per, (k + 1) * per)) for k in range(nb)]
+    batches += [[nb * per + 1, nb * per + 3], [nb * per, nb * per + 2], [nb * per + 4]]          # the last one is never delivered
+    own = torch.randint(-30000, 30000, (per * n,), generator=g, dtype=torch.int16)             # rank 0's batch: host
+    big = torch.randint(-30000, 30000, ((nb - 1) * per * n + 1000,), generator=g, dtype=torch.int16)
+    big_dev = big.to(dev)
+    served = [3, 0, 7, 1, 5, 2, 6]                                                           # arrival order of the other batches
+    pieces = [(4, own, 0, [n] * per)]
+    for j, k in enumerate(served):
+        pieces.append((k, big_dev, j * per * n, [n] * per))
+    tail = (nb - 1) * per * n
+    pieces.append((nb, big_dev, tail, [100, 300]))
+    pieces.append((nb + 1, big_dev, tail + 400, [50, 250]))
+    out = place_pieces(pieces, batches, nb * per + 5, dev)
+    exp = [None] * nb
+    exp[4] = own
+    for j, k in enumerate(served):
+        exp[k] = big[j * per * n:(j + 1) * per * n]
+    t = big[tail:]
+    exp += [t[400:450], t[0:100], t[450:700], t[100:400]]                                       # segments nb*per + 0 .. 3; + 4 stays empty
+    exp = torch.cat(exp).numpy()
+    assert out.dtype == np.int16 and out.shape == exp.shape and np.array_equal(out, exp)
+    t0 = time.perf_counter()
+    place_pieces(pieces, batches, nb * per + 5, dev)
+    print(f"[gather] 8 x 8.2 MB placed in {1e3 * (time.perf_counter() - t0):.2f} ms")

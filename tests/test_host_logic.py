@@ -185,6 +185,8 @@ def _gloo_worker(rank, world, port, q, mode):
         sh = sharding.ShardedSynthesizer(synth, torch.device("cpu"), dynamic=mode not in ("static", "fail"))   # static dealing: the failing rank is sure to own a batch
         if mode == "many" and rank == 0:
             segs = [{"phones": [i % 50 + 1] * 2, "bert_features": None, "norm_text": "x" * (i + 1)} for i in range(24)]
+        if mode == "equal" and rank == 0:       # equal lengths: every batch is a run of consecutive segments (configs[1]'s step)
+            segs = [{"phones": [i + 1] * 3, "bert_features": None, "norm_text": "x" * 3} for i in range(8)]
         if mode in ("stream", "slow_rank1", "fail0_stream", "many"):
             order, flat = [], []
             try:
@@ -245,6 +247,15 @@ def test_sharded_streaming_yields_batches_in_order_with_work_queue(world):
     assert all(0 <= o < world for o in r0["owner"])                     # who served which batch is the queue's business
     assert sum(len(res[r]["calls"]) for r in range(world)) == 4
     assert all(res[r]["order"] == [] for r in range(1, world))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_run_places_whole_batches_of_consecutive_segments(world):
+    """equal-length utterances (the benchmark step): each rank's batch is one run of consecutive segments and lands in the
+    result buffer as ONE copy; the order must still be the submission order whoever served which batch."""
+    res = _run_gloo(world, "equal", 97)
+    assert res[0]["out"] == sum(([i + 1] * 30 for i in range(8)), [])
+    assert sum(sum(res[r]["calls"]) for r in range(world)) == 8
 
 
 def test_sharded_bert_features_are_shipped_and_failures_propagate():
