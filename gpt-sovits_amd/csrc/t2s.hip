@@ -146,6 +146,32 @@ __global__ __launch_bounds__(256) void prefill_vt_kernel(const _Float16* __restr
   for (int i = ty; i < 32; i += 8) vt[(((long long)b * H + h) * 32 + i) * spad + j0 + tx] = tile[tx][i];
 }
 
+// The same V^T tiles plus the head-major K/V cache rows of those 32 positions: one launch per layer instead of
+// kv_scatter_kernel + prefill_vt_kernel (a 32 x 32 tile of one head is 2 KB contiguous in either cache).
+__global__ __launch_bounds__(256) void prefill_kvt_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ row_off,
+                                                          const int* __restrict__ x_len, int P, int d, int H, int smax, int spad,
+                                                          _Float16* __restrict__ kc, _Float16* __restrict__ vc,
+                                                          _Float16* __restrict__ vt) {
+  __shared__ _Float16 tile[32][34];
+  const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * 32;
+  const int S = x_len[b] + P;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int j = j0 + i;
+    _Float16 v = (_Float16)0.f;
+    if (j < S) {
+      const _Float16* src = qkv + (long long)(row_off[b] + j) * 3 * d + h * 32 + tx;
+      const long long o = (((long long)b * H + h) * smax + j) * 32 + tx;
+      v = src[2 * d];
+      kc[o] = src[d];
+      vc[o] = v;
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) vt[(((long long)b * H + h) * 32 + i) * spad + j0 + tx] = tile[tx][i];
+}
+
 template <int QT>
 __global__ __launch_bounds__(256) void prefill_flash32_f16_kernel(const _Float16* __restrict__ qkv, const _Float16* __restrict__ kc,
                                                                    const _Float16* __restrict__ vt, const int* __restrict__ row_off,
@@ -1430,6 +1456,7 @@ int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_le
   GSV_HIP(hipGetLastError());
 
   static const bool scalar_pf = getenv("GSV_SCALAR_PREFILL_ATTN") != nullptr;   // A/B switch: thread-per-query VALU kernel
+  static const bool split_scatter = getenv("GSV_PREFILL_SPLIT_SCATTER") != nullptr;   // A/B switch: K/V scatter and V^T as two launches
   for (int li = 0; li < c.n_layer; ++li) {
     const LayerW& L = h->layers[li];
     ConvArgs g;
@@ -1437,10 +1464,17 @@ int gsv_t2s_prefill(gsv_t2s_t* h, const int32_t* phones, const int32_t* phone_le
     g.T_in = M; g.T_out = M; g.T_virt = M; g.Cin = d; g.Cout = 3 * d; g.ldx = d; g.ldw = d; g.ldy = 3 * d;
     GSV_RC(launch_conv_gemm(h->dtype, g, s));
     if (h->dtype == GSV_F16) {
-      hipLaunchKernelGGL(kv_scatter_kernel<_Float16>, dim3(maxS, B), dim3(128), 0, s, (const _Float16*)h->pf_qkv,
-                         h->d_row_off, h->d_x_len, P, d, H, h->max_seq, (_Float16*)kv_ptr(h, li, 0), (_Float16*)kv_ptr(h, li, 1));
+      const bool fused_kvt = d / H == 32 && !scalar_pf && !split_scatter;
+      if (!fused_kvt)
+        hipLaunchKernelGGL(kv_scatter_kernel<_Float16>, dim3(maxS, B), dim3(128), 0, s, (const _Float16*)h->pf_qkv,
+                           h->d_row_off, h->d_x_len, P, d, H, h->max_seq, (_Float16*)kv_ptr(h, li, 0), (_Float16*)kv_ptr(h, li, 1));
       if (d / H == 32 && !scalar_pf) {
         const int spad = (maxS + 31) / 32 * 32;
+        if (fused_kvt)
+          hipLaunchKernelGGL(prefill_kvt_kernel, dim3(spad / 32, H, B), dim3(256), 0, s, (const _Float16*)h->pf_qkv, h->d_row_off,
+                             h->d_x_len, P, d, H, h->max_seq, spad, (_Float16*)kv_ptr(h, li, 0), (_Float16*)kv_ptr(h, li, 1),
+                             (_Float16*)h->pf_vt);
+        else
         hipLaunchKernelGGL(prefill_vt_kernel, dim3(spad / 32, H, B), dim3(256), 0, s, (const _Float16*)h->pf_qkv, h->d_row_off,
                            h->d_x_len, P, d, H, spad, (_Float16*)h->pf_vt);
         hipLaunchKernelGGL(prefill_flash32_f16_kernel<4>, dim3(cdiv(maxS, 64), H, B), dim3(256), 0, s, (const _Float16*)h->pf_qkv,
